@@ -1,0 +1,107 @@
+/* oracle/gi_oracle.h -- C ABI of the CPU oracle (TEST INFRASTRUCTURE, not the product).
+ *
+ * The oracle is a plain double-precision CPU restatement of the reference render hot path
+ * (moepforfreedom/GI_Raytracer: include/raytracer.h, octree.cpp, photonMap.cpp, entities.h, util.{h,cpp},
+ * halton_enum.h, halton_sampler.h).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it, and only as the checker.  The product (gi_raytracer_amd/, include/gi_hip.h) never links it.
+ */
+#ifndef GI_ORACLE_H
+#define GI_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gio_ctx gio_ctx;
+
+/* RNG contract ---------------------------------------------------------------------------------------------
+ * GIO_RNG_COUNTER: u = U(seed, stream, depth, purpose, a, b)   (stateless; shared with the HIP path)
+ * GIO_RNG_CHAIN  : the reference's sequential xorshift64* (include/util.h:52-80) seeded with `seed`
+ *                  (the reference seeds it with time(0)); single-threaded; used only to pin the oracle
+ *                  against determinised runs of the real reference.                                          */
+enum { GIO_RNG_COUNTER = 0, GIO_RNG_CHAIN = 1 };
+
+gio_ctx* gio_create(void);
+/* GIO_RNG_CHAIN state of this context (the reference seeds its chain with time(0)); emit_photons and render
+ * continue one chain in call order, exactly as one reference process does.  `seed` arguments are ignored in chain mode. */
+int gio_chain_seed(gio_ctx*, uint64_t seed);
+void gio_destroy(gio_ctx*);
+
+/* Scene tables (all caller-owned, copied).
+ * ent_kind[i]: 0 triangle, 1 sphere (centre = pos[i][0], radius = pos[i][1].x).
+ * pos/nrm: [n][3][3], uv: [n][3][2], mat_idx: [n]; mats: [nmat][9] = roughness, opacity, IOR, diffuse rgb, emissive rgb
+ * lights: [nlight][7] = pos, col, rad.                                                                       */
+int gio_set_scene(gio_ctx*, int n_ent, const int32_t* ent_kind, const double* pos, const double* nrm, const double* uv,
+                  const int32_t* mat_idx, int n_mat, const double* mats, int n_light, const double* lights,
+                  const double* ambient3);
+/* camera: pos(3) up(3) forward(3) sensorDiag focalDist  (include/camera.h) */
+int gio_set_camera(gio_ctx*, const double* cam11);
+
+/* Octree::rebuild (include/octree.cpp:53-119): light dir/angle precompute + recursive partition. */
+int gio_build_octree(gio_ctx*);
+int gio_octree_counts(gio_ctx*, int32_t* n_nodes, int32_t* n_refs);
+/* pre-order dump: bbox [n][6], child [n][8] (-1 = null), ent_off [n+1], ent_idx [n_refs] */
+int gio_octree_dump(gio_ctx*, double* bbox, int32_t* child, int32_t* ent_off, int32_t* ent_idx);
+int gio_get_lights(gio_ctx*, double* dir_angle /* [nlight][4] */);
+int gio_ent_bbox(gio_ctx*, double* bbox /* [n_ent][6] */);
+
+/* RayTracer::trace (include/raytracer.h:382-478) on explicit rays [n][6] (origin, unit dir).
+ * res [n][8] = hit(3) normal(3) uv(2); n_leaves = size of the sorted leaf list.                              */
+int gio_trace(gio_ctx*, int n, const double* rays, int32_t* hit, int32_t* ent, double* res, int32_t* n_leaves);
+/* sorted leaf list of one ray: returns count, fills up to cap entries (node pre-order index, t0) */
+int gio_leaf_order(gio_ctx*, const double* ray6, int cap, int32_t* node, double* t0);
+/* RayTracer::visible (include/raytracer.h:280-319): q [n][6] = origin, target point; mt = |target-origin|^2 */
+int gio_visible(gio_ctx*, int n, const double* q, int32_t* vis, int32_t* n_cand);
+
+/* Photons: [n][9] = origin, dir, col (include/photon.h). */
+int gio_set_photons(gio_ctx*, int n, const double* photons);
+int gio_photon_count(gio_ctx*);
+int gio_get_photons(gio_ctx*, double* photons);
+/* RayTracer::tracePhotons (include/raytracer.h:582-715); returns number stored; tries_out = total emission tries */
+int gio_emit_photons(gio_ctx*, int count, int max_depth, int rng_mode, uint64_t seed, int64_t* tries_out);
+/* PhotonMap::rebuild (include/photonMap.cpp:33-47) */
+int gio_build_photon_map(gio_ctx*);
+int gio_pmap_counts(gio_ctx*, int32_t* n_nodes, int32_t* n_refs);
+/* pre-order dump: bbox [n][6], first_child [n] (-1 = leaf; children are 8 consecutive sub-trees), off [n+1], idx [n_refs] */
+int gio_pmap_dump(gio_ctx*, double* bbox, int32_t* first_child, int32_t* off, int32_t* idx);
+/* RayTracer::samplePhotons (include/raytracer.h:532-579): q [n][6] = pos, dir */
+int gio_gather(gio_ctx*, int n, const double* q, double* res3, int32_t* n_cand);
+
+/* RayTracer::run pixel loop (include/raytracer.h:74-160) over rows [y0,y1) of a w x h frame.
+ * out_lin: [h][w][3] linear (pre-gamma, unclamped) running-mean radiance, rows outside [y0,y1) untouched.
+ * out_u8 (optional): [h][w][3] gamma 2.2 / clamp / (int)(255 c) as Image::setPixel (include/image.h:14-16).
+ * out_spp (optional): [h][w] samples taken.  counters (optional) [8]: node visits (trace), node visits (shadow),
+ * triangle tests, shaded hits, photon candidates, trace calls, shadow rays, gathers.
+ * chain_predraws: GIO_RNG_CHAIN only -- drand() draws discarded before the pixel loop (RayTracer::run's two
+ * subrand() calls, include/raytracer.h:87-90).                                                               */
+int gio_render(gio_ctx*, int w, int h, int y0, int y1, int min_samples, int max_samples, double noise_thresh,
+               int rng_mode, uint64_t seed, int chain_predraws, int n_threads,
+               double* out_lin, uint8_t* out_u8, int32_t* out_spp, int64_t* counters);
+
+/* radiance() of explicit primary rays under the counter RNG: rays [n][6], stream[n] = halton sample index */
+int gio_radiance(gio_ctx*, int n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3);
+
+/* known-answer helpers ------------------------------------------------------------------------------------ */
+int gio_halton_enum_params(int w, int h, uint32_t* out5 /* p2 p3 m_x m_y increment */);
+uint32_t gio_halton_index(int w, int h, uint32_t s, uint32_t x, uint32_t y);
+float gio_halton_scale(int w, int h, int axis, float v);
+float gio_halton_sample(uint32_t dim, uint32_t index);
+double gio_fast_pow(double a, double b);
+double gio_fast_precise_pow(double a, double b);
+void gio_hemi_cos_n(const double* n3, float u, float v, double power, double* out3);
+void gio_hemi_cos(float u, float v, double power, double* out3);
+void gio_sample_phong(const double* outdir3, const double* n3, double power, double sx, double sy, double* out3);
+void gio_sphere_cap(const double* n3, float u, float v, double power, double frac, double* out3);
+void gio_unit_vec(double x, double y, double* out3);
+void gio_refr(const double* inc3, const double* n3, double eta, double* out3);
+void gio_reflect(const double* inc3, const double* n3, double* out3);
+int gio_tri_box_overlap(const double* center3, const double* half3, const double* verts9);
+double gio_chain_drand(uint64_t* state);
+double gio_counter_rand(uint64_t seed, uint32_t stream, uint32_t depth, uint32_t purpose, uint32_t a, uint32_t b);
+/* primary ray of sample s at pixel (x,y): out ray6, returns halton index */
+uint32_t gio_primary_ray(gio_ctx*, int w, int h, int s, int x, int y, double* ray6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
