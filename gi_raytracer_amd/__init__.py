@@ -1,0 +1,373 @@
+"""gi_raytracer_amd -- Python host mirror of the MI355X render hot path of GI_Raytracer.
+
+Thin ctypes binding over the C ABI (include/gi_hip.h, gi_raytracer_amd/csrc/gi_host.h) of libgi_raytracer_hip.so.
+The names mirror the reference's C++ surface for this path: `Scene` plays Octree (+ the loaders that fill it),
+`RayTracer` plays RayTracer (setScene / run / trace / visible / samplePhotons / tracePhotons).  There is no CPU
+implementation behind these classes: creating a RayTracer without the HIP library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgi_raytracer_hip.so")
+DEFAULT_SEED = 0x9E3779B97F4A7C15
+
+GI_OK, GI_E_NO_DEVICE, GI_E_INVALID, GI_E_HIP, GI_E_STATE, GI_E_CANCELLED = 0, -1, -2, -3, -4, -5
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint32)
+
+
+class GiError(RuntimeError):
+    pass
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_tri", C.c_int32), ("tri_pos", _dp), ("tri_nrm", _dp), ("tri_uv", _dp), ("tri_mat", _ip),
+                ("n_mat", C.c_int32), ("mats", _dp), ("n_light", C.c_int32), ("lights", _dp), ("ambient", C.c_double * 3),
+                ("n_node", C.c_int32), ("node_bbox", _dp), ("node_child", _ip), ("node_ent_off", _ip), ("node_ent_idx", _ip)]
+
+
+class PhotonMapDesc(C.Structure):
+    _fields_ = [("n_photon", C.c_int32), ("photons", _dp), ("n_node", C.c_int32), ("node_bbox", _dp), ("node_child", _ip),
+                ("node_off", _ip), ("node_idx", _ip)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("cam_pos", C.c_double * 3), ("cam_up", C.c_double * 3), ("cam_forward", C.c_double * 3),
+                ("sensor_diag", C.c_double), ("focal_dist", C.c_double), ("width", C.c_int32), ("height", C.c_int32),
+                ("stripe_h", C.c_int32), ("stripe_rank", C.c_int32), ("stripe_world", C.c_int32),
+                ("min_samples", C.c_int32), ("max_samples", C.c_int32), ("noise_thresh", C.c_double), ("seed", C.c_uint64)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("photons", C.c_int32), ("photon_depth", C.c_int32), ("min_samples", C.c_int32), ("max_samples", C.c_int32),
+                ("noise_thresh", C.c_double), ("ambient", C.c_double * 3), ("cam_pos", C.c_double * 3), ("cam_up", C.c_double * 3),
+                ("cam_forward", C.c_double * 3), ("sensor_diag", C.c_double), ("focal_dist", C.c_double)]
+
+
+_LIB = None
+
+# every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
+    "gi_render_device", "gi_render_host", "gi_last_render_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
+    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index",
+    "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
+    "gih_add_light", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
+    "gih_counts", "gih_build_photon_map", "gih_get_photon_desc",
+]
+
+
+def lib():
+    """Load libgi_raytracer_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise GiError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.gi_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.gi_destroy.argtypes = [vp]
+    L.gi_last_error.argtypes = [vp]
+    L.gi_last_error.restype = C.c_char_p
+    L.gi_set_stream.argtypes = [vp, vp]
+    L.gi_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.gi_upload_photons.argtypes = [vp, C.POINTER(PhotonMapDesc)]
+    L.gi_local_rows.argtypes = [C.POINTER(RenderParams)]
+    L.gi_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int, vp, vp]
+    L.gi_render_host.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int, vp, vp]
+    L.gi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), _ip]
+    L.gi_set_counters.argtypes = [vp, C.c_int]
+    L.gi_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.gi_trace.argtypes = [vp, C.c_int32, _dp, _ip, _ip, _dp]
+    L.gi_visible.argtypes = [vp, C.c_int32, _dp, _ip]
+    L.gi_gather.argtypes = [vp, C.c_int32, _dp, _dp, _ip]
+    L.gi_radiance.argtypes = [vp, C.c_int32, _dp, _up, C.c_uint64, _dp]
+    L.gi_emit_photons.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint64, _dp, C.c_int32, C.POINTER(C.c_int64)]
+    L.gi_halton_sample.argtypes = [vp, C.c_int32, _up, _up, C.POINTER(C.c_float)]
+    L.gi_halton_index.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _up, _up]
+    L.gih_scene_create.restype = vp
+    L.gih_scene_destroy.argtypes = [vp]
+    L.gih_last_error.argtypes = [vp]
+    L.gih_last_error.restype = C.c_char_p
+    L.gih_load_scn.argtypes = [vp, C.c_char_p]
+    L.gih_add_material.argtypes = [vp, _dp]
+    L.gih_add_triangles.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _ip]
+    L.gih_add_light.argtypes = [vp, _dp, _dp, C.c_double]
+    L.gih_set_ambient.argtypes = [vp, _dp]
+    L.gih_get_settings.argtypes = [vp, C.POINTER(Settings)]
+    L.gih_set_camera.argtypes = [vp, _dp, _dp]
+    L.gih_build_octree.argtypes = [vp]
+    L.gih_get_scene_desc.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.gih_counts.argtypes = [vp, _ip, _ip, _ip, _ip, _ip]
+    L.gih_build_photon_map.argtypes = [vp, C.c_int32, _dp]
+    L.gih_get_photon_desc.argtypes = [vp, C.POINTER(PhotonMapDesc)]
+    _LIB = L
+    return L
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _p(a, ty=_dp):
+    return a.ctypes.data_as(ty) if a is not None else None
+
+
+def _np_from(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape).copy()
+
+
+class Scene:
+    """Host-side scene = the reference's Octree plus what its loaders write into RayTracer (include/octree.h:39-64,
+    include/sceneLoader.cpp).  Build order as in the reference: push entities / lights, `rebuild()`, then render."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.gih_scene_create())
+
+    def __del__(self):
+        try:
+            self.L.gih_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    def _err(self):
+        return self.L.gih_last_error(self.h).decode()
+
+    @classmethod
+    def load(cls, scn_path):
+        """loadScene(scene, raytracer, path) (include/sceneLoader.cpp:12)."""
+        s = cls()
+        rc = s.L.gih_load_scn(s.h, os.fsencode(scn_path))
+        if rc != 0:
+            raise GiError(f"load_scn({scn_path}): {s._err()}")
+        return s
+
+    def add_material(self, roughness, opacity, ior, diffuse, emissive=(0, 0, 0)):
+        m = _f64([roughness, opacity, ior, *diffuse, *emissive])
+        return self.L.gih_add_material(self.h, _p(m))
+
+    def add_triangles(self, pos, nrm=None, uv=None, mat_idx=None):
+        pos = _f64(pos).reshape(-1, 3, 3)
+        n = len(pos)
+        nrm = _f64(nrm).reshape(n, 3, 3) if nrm is not None else None
+        uv = _f64(uv).reshape(n, 3, 2) if uv is not None else None
+        mi = np.ascontiguousarray(mat_idx if mat_idx is not None else np.zeros(n), np.int32)
+        rc = self.L.gih_add_triangles(self.h, n, _p(pos), _p(nrm), _p(uv), _p(mi, _ip))
+        if rc != 0:
+            raise GiError(self._err())
+
+    def add_light(self, pos, col, rad):
+        self.L.gih_add_light(self.h, _p(_f64(pos)), _p(_f64(col)), float(rad))
+
+    def set_ambient(self, rgb):
+        self.L.gih_set_ambient(self.h, _p(_f64(rgb)))
+
+    def set_camera(self, pos, look_at):
+        self.L.gih_set_camera(self.h, _p(_f64(pos)), _p(_f64(look_at)))
+
+    @property
+    def settings(self):
+        st = Settings()
+        self.L.gih_get_settings(self.h, C.byref(st))
+        return st
+
+    def rebuild(self):
+        """Octree::rebuild (include/octree.cpp:53-119)."""
+        rc = self.L.gih_build_octree(self.h)
+        if rc != 0:
+            raise GiError(f"build_octree: {self._err()}")
+        return self
+
+    def desc(self):
+        d = SceneDesc()
+        rc = self.L.gih_get_scene_desc(self.h, C.byref(d))
+        if rc != 0:
+            raise GiError("scene octree not built: call rebuild() first")
+        return d
+
+    def tables(self):
+        """Numpy copies of the flattened tables (tests)."""
+        d = self.desc()
+        nref = _np_from(d.node_ent_off, (d.n_node + 1,), np.int32)[-1]
+        return {
+            "tri_pos": _np_from(d.tri_pos, (d.n_tri, 3, 3), np.float64), "tri_nrm": _np_from(d.tri_nrm, (d.n_tri, 3, 3), np.float64),
+            "tri_uv": _np_from(d.tri_uv, (d.n_tri, 3, 2), np.float64), "tri_mat": _np_from(d.tri_mat, (d.n_tri,), np.int32),
+            "mats": _np_from(d.mats, (d.n_mat, 9), np.float64), "lights": _np_from(d.lights, (d.n_light, 11), np.float64),
+            "ambient": np.array(list(d.ambient)), "node_bbox": _np_from(d.node_bbox, (d.n_node, 6), np.float64),
+            "node_child": _np_from(d.node_child, (d.n_node, 8), np.int32), "node_ent_off": _np_from(d.node_ent_off, (d.n_node + 1,), np.int32),
+            "node_ent_idx": _np_from(d.node_ent_idx, (int(nref),), np.int32),
+        }
+
+    def build_photon_map(self, photons):
+        """PhotonMap::push_back x n + rebuild (include/photonMap.cpp:24-47)."""
+        ph = _f64(photons).reshape(-1, 9)
+        rc = self.L.gih_build_photon_map(self.h, len(ph), _p(ph))
+        if rc != 0:
+            raise GiError(f"build_photon_map: {self._err()}")
+        return self
+
+    def photon_desc(self):
+        d = PhotonMapDesc()
+        self.L.gih_get_photon_desc(self.h, C.byref(d))
+        return d
+
+    def photon_tables(self):
+        d = self.photon_desc()
+        nref = _np_from(d.node_off, (d.n_node + 1,), np.int32)[-1] if d.n_node else 0
+        return {"photons": _np_from(d.photons, (d.n_photon, 9), np.float64), "node_bbox": _np_from(d.node_bbox, (d.n_node, 6), np.float64),
+                "node_child": _np_from(d.node_child, (d.n_node, 8), np.int32), "node_off": _np_from(d.node_off, (d.n_node + 1,), np.int32) if d.n_node else np.zeros(1, np.int32),
+                "node_idx": _np_from(d.node_idx, (int(nref),), np.int32)}
+
+
+class RayTracer:
+    """Device context = the reference's RayTracer for this path (include/raytracer.h:23-735)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.gi_create(C.byref(h), int(device))
+        if rc != GI_OK:
+            raise GiError(f"gi_create failed ({rc}): no usable HIP device -- this path has no CPU fallback")
+        self.h = h
+        self.scene = None
+        st = Scene().settings  # reference defaults (include/util.h:24-29, main.cpp:28)
+        self.photons, self.photon_depth = st.photons, st.photon_depth
+        self.min_samples, self.max_samples, self.noise_thresh = st.min_samples, st.max_samples, st.noise_thresh
+        self.cam_pos, self.cam_up, self.cam_forward = list(st.cam_pos), list(st.cam_up), list(st.cam_forward)
+        self.sensor_diag, self.focal_dist = st.sensor_diag, st.focal_dist
+        self.seed = DEFAULT_SEED
+
+    def __del__(self):
+        try:
+            self.L.gi_destroy(self.h)
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise GiError(f"{what}: {self.L.gi_last_error(self.h).decode()} ({rc})")
+        return rc
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.gi_set_stream(self.h, C.c_void_p(stream_ptr)), "set_stream")
+
+    def setScene(self, scene, adopt_settings=True):
+        """RayTracer::setScene (include/raytracer.h:35-39) + upload of the flattened tables."""
+        d = scene.desc()
+        self._check(self.L.gi_upload_scene(self.h, C.byref(d)), "upload_scene")
+        self.scene = scene
+        if adopt_settings:
+            st = scene.settings
+            self.photons, self.photon_depth = st.photons, st.photon_depth
+            self.min_samples, self.max_samples, self.noise_thresh = st.min_samples, st.max_samples, st.noise_thresh
+            self.cam_pos, self.cam_up, self.cam_forward = list(st.cam_pos), list(st.cam_up), list(st.cam_forward)
+            self.sensor_diag, self.focal_dist = st.sensor_diag, st.focal_dist
+        return self
+
+    def upload_photon_map(self):
+        d = self.scene.photon_desc()
+        self._check(self.L.gi_upload_photons(self.h, C.byref(d)), "upload_photons")
+
+    def tracePhotons(self, count=None, max_depth=5, seed=None):
+        """RayTracer::tracePhotons(5, photons, ...) on the device, then PhotonMap::rebuild on the host and upload
+        (include/raytracer.h:61-72,582-715).  Returns (photons [n][9], emission tries)."""
+        count = self.photons if count is None else count
+        n_light = self.scene.desc().n_light
+        cap = max(count * max(n_light, 1), 1)
+        out = np.zeros((cap, 9))
+        tries = C.c_int64()
+        n = self._check(self.L.gi_emit_photons(self.h, count, max_depth, C.c_uint64(self.seed if seed is None else seed), _p(out), cap, C.byref(tries)), "emit_photons")
+        ph = out[:n].copy()
+        self.scene.build_photon_map(ph)
+        self.upload_photon_map()
+        return ph, tries.value
+
+    def params(self, w, h, stripe_h=None, rank=0, world=1, min_samples=None, max_samples=None, noise_thresh=None, seed=None):
+        p = RenderParams()
+        p.cam_pos[:] = self.cam_pos; p.cam_up[:] = self.cam_up; p.cam_forward[:] = self.cam_forward
+        p.sensor_diag, p.focal_dist = self.sensor_diag, self.focal_dist
+        p.width, p.height = w, h
+        p.stripe_h, p.stripe_rank, p.stripe_world = (h if stripe_h is None else stripe_h), rank, world
+        p.min_samples = self.min_samples if min_samples is None else min_samples
+        p.max_samples = self.max_samples if max_samples is None else max_samples
+        p.noise_thresh = self.noise_thresh if noise_thresh is None else noise_thresh
+        p.seed = self.seed if seed is None else seed
+        return p
+
+    def local_rows(self, p):
+        return self.L.gi_local_rows(C.byref(p))
+
+    def run(self, w, h, f64=True, want_spp=False, **kw):
+        """RayTracer::run(w, h) pixel loop -> linear radiance [rows][w][3] on the host."""
+        p = self.params(w, h, **kw)
+        rows = self.local_rows(p)
+        out = np.zeros((rows, w, 3), np.float64 if f64 else np.float32)
+        spp = np.zeros((rows, w), np.int32) if want_spp else None
+        self._check(self.L.gi_render_host(self.h, C.byref(p), out.ctypes.data_as(C.c_void_p), 1 if f64 else 0,
+                                          spp.ctypes.data_as(C.c_void_p) if want_spp else None, None), "render_host")
+        return (out, spp) if want_spp else out
+
+    def run_device(self, p, out_ptr, f64=False, spp_ptr=None):
+        """Render into device memory (bench / multi-GPU path); out_ptr is a raw device pointer."""
+        self._check(self.L.gi_render_device(self.h, C.byref(p), C.c_void_p(out_ptr), 1 if f64 else 0, C.c_void_p(spp_ptr) if spp_ptr else None, None), "render_device")
+
+    def last_render_ms(self):
+        ms, n = C.c_float(), C.c_int32()
+        self._check(self.L.gi_last_render_ms(self.h, C.byref(ms), C.byref(n)), "last_render_ms")
+        return ms.value, n.value
+
+    def set_counters(self, on):
+        self.L.gi_set_counters(self.h, 1 if on else 0)
+
+    def counters(self):
+        out = (C.c_int64 * 8)()
+        self._check(self.L.gi_get_counters(self.h, out), "get_counters")
+        return np.array(list(out), np.int64)
+
+    def trace(self, rays):
+        rays = _f64(rays).reshape(-1, 6)
+        n = len(rays)
+        hit = np.zeros(n, np.int32); ent = np.zeros(n, np.int32); res = np.zeros((n, 8))
+        self._check(self.L.gi_trace(self.h, n, _p(rays), _p(hit, _ip), _p(ent, _ip), _p(res)), "trace")
+        return hit, ent, res
+
+    def visible(self, q):
+        q = _f64(q).reshape(-1, 6)
+        vis = np.zeros(len(q), np.int32)
+        self._check(self.L.gi_visible(self.h, len(q), _p(q), _p(vis, _ip)), "visible")
+        return vis
+
+    def samplePhotons(self, q):
+        q = _f64(q).reshape(-1, 6)
+        res = np.zeros((len(q), 3)); nc = np.zeros(len(q), np.int32)
+        self._check(self.L.gi_gather(self.h, len(q), _p(q), _p(res), _p(nc, _ip)), "gather")
+        return res, nc
+
+    def radiance(self, rays, stream, seed=None):
+        rays = _f64(rays).reshape(-1, 6)
+        stream = np.ascontiguousarray(stream, np.uint32)
+        out = np.zeros((len(rays), 3))
+        self._check(self.L.gi_radiance(self.h, len(rays), _p(rays), _p(stream, _up), C.c_uint64(self.seed if seed is None else seed), _p(out)), "radiance")
+        return out
+
+    def halton_sample(self, dim, index):
+        dim = np.ascontiguousarray(dim, np.uint32); index = np.ascontiguousarray(index, np.uint32)
+        out = np.zeros(len(dim), np.float32)
+        self._check(self.L.gi_halton_sample(self.h, len(dim), _p(dim, _up), _p(index, _up), out.ctypes.data_as(C.POINTER(C.c_float))), "halton_sample")
+        return out
+
+    def halton_index(self, w, h, sxy):
+        sxy = np.ascontiguousarray(sxy, np.uint32).reshape(-1, 3)
+        out = np.zeros(len(sxy), np.uint32)
+        self._check(self.L.gi_halton_index(self.h, w, h, len(sxy), _p(sxy, _up), _p(out, _up)), "halton_index")
+        return out

@@ -1,0 +1,699 @@
+// gi_device.h -- per-lane device functions of the MI355X render hot path (one ray / one pixel per lane).
+//
+// Everything here is plain scalar-per-lane code marked GI_HD so that the very same functions can also be compiled
+// for the host by tests/host_emul (a CPU build used ONLY by unit tests and sanitizers to check the kernel logic
+// without a GPU; the product library never contains it).  Wave-level code (ballots, atomics, LDS carving, launches)
+// lives in gi_kernels.hip.
+//
+// Reference semantics followed (file:line relative to moepforfreedom/GI_Raytracer):
+//   trace            include/raytracer.h:382-478 + include/octree.cpp:188-211,285-313 + include/bbox.h:47-73
+//   visible          include/raytracer.h:280-319 + include/octree.cpp:150-185,256-282 + include/bbox.h:117-138
+//   triangle test    include/entities.h:443-490
+//   secondaryRay     include/raytracer.h:321-379, rayType :481-506
+//   radiance         include/raytracer.h:167-276 (recursion turned into a loop carrying the path throughput)
+//   samplePhotons    include/raytracer.h:532-579 + include/photonMap.cpp:50-134
+//   tracePhotons     include/raytracer.h:582-715
+//   samplers         include/util.cpp:27-107, include/util.h:100-188
+//   Halton           include/halton_enum.h:106-155, include/halton_sampler.h:626-888,1417-3286
+// Arithmetic keeps the reference's operand order (glm 0.9.8 conventions) and is compiled with -ffp-contract=off so that
+// hit/miss and traversal decisions agree with the CPU path; see DESIGN.md "Numerics".
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#ifndef GI_HD
+#define GI_HD __host__ __device__ __forceinline__
+#endif
+
+namespace gi {
+
+// ------------------------------------------------------------------------------------------------ constants (include/util.h:14-31)
+#define GI_EPSILON 0.00001
+#define GI_SHADOW_BIAS 0.0001
+#define GI_MIN_DEPTH 2
+#define GI_MAX_DEPTH 64
+#define GI_PI 3.14159265358979323846
+#define GI_GATHER_K 32
+
+// ------------------------------------------------------------------------------------------------ device tables (HBM layout)
+struct TNode {              // 64 B: one node of one of the 8 direction-ordered pre-order copies of the scene octree
+    double bmin[3], bmax[3];
+    int32_t skip;           // next node when this sub-tree is skipped (END = n_node)
+    int32_t first_ref;      // leaves: first entry in leaf_refs
+    int32_t n_ref;          // leaves: number of entries; inner nodes: -1
+    int32_t leaf_id;        // canonical pre-order index (RNG key, same numbering as the CPU side)
+};
+struct TriGeom {            // 80 B: what a ray-triangle test needs
+    double p0[3], e1[3], e2[3];
+    int32_t mat;
+    uint32_t flags;         // bit0: interpolate vertex normals; bit1: alpha test always passes (opacity >= 1 or IOR != 1)
+};
+struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; };  // 96 B, read once per shaded hit
+struct Mat { double roughness, opacity, ior, diffuse[3], emissive[3]; };
+struct LightD { double pos[3], col[3], rad, dir[3], angle; };
+struct PNode {              // 64 B: photon octree node, pre-order with skip links; photons are stored in leaf order
+    double bmin[3], bmax[3];
+    int32_t skip, first, count, is_leaf;
+};
+struct HaltonDim { uint32_t P, n, off; float scale; };
+
+struct Scene {
+    const TNode* tnodes;      // [8][n_node]
+    const int32_t* leaf_refs;
+    const TriGeom* tris;
+    const TriShade* shade;
+    const Mat* mats;
+    const LightD* lights;
+    const PNode* pnodes;
+    const double* ph_pos;     // [n_photon][3] leaf order
+    const double* ph_dircol;  // [n_photon][6] leaf order
+    const HaltonDim* hdims;   // [256]
+    const uint16_t* htable;
+    int32_t n_node, n_tri, n_light, n_pnode, n_photon;
+    double ambient[3];
+};
+
+struct Counters { unsigned long long v_trace, v_shadow, tri, shaded, pcand, traces, shadows, gathers; };
+
+// ------------------------------------------------------------------------------------------------ vec3 in glm operand order
+struct V3 { double x, y, z; };
+GI_HD V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+GI_HD V3 ld3(const double* p) { return v3(p[0], p[1], p[2]); }
+GI_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+GI_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+GI_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+GI_HD V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+GI_HD V3 operator*(double s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+GI_HD V3 operator/(V3 a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+GI_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+GI_HD V3 cross(V3 x, V3 y) { return v3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+GI_HD V3 normalize(V3 v) { return v * (1.0 / sqrt(dot(v, v))); }
+GI_HD double length(V3 v) { return sqrt(dot(v, v)); }
+GI_HD V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.0; }
+GI_HD V3 mix(V3 x, V3 y, double a) { return x + a * (y - x); }
+GI_HD double len2(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+GI_HD double comp_max(V3 v) { return fmax(fmax(v.x, v.y), v.z); }
+
+struct Ray { V3 o, d, inv; };
+GI_HD Ray make_ray(V3 o, V3 d)  // Ray ctor / setDir, include/ray.h:7-17
+{
+    Ray r;
+    r.o = o;
+    r.d = normalize(d);
+    r.inv = v3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    return r;
+}
+GI_HD Ray make_ray_exact(V3 o, V3 d)
+{
+    Ray r;
+    r.o = o; r.d = d;
+    r.inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ counter RNG (DESIGN.md "RNG contract")
+GI_HD uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27; z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+enum {
+    P_TRACE_ALPHA = 0, P_SHADOW_ALPHA = 1, P_LIGHT_X = 2, P_LIGHT_Y = 3, P_TYPE_OPACITY = 4, P_TYPE_FRESNEL = 5,
+    P_RR = 6, P_FOG = 7, P_TRACE_GUARD = 8,
+    P_PH_DIR_U = 16, P_PH_DIR_V = 17, P_PH_SEC_U = 18, P_PH_SEC_V = 19, P_PH_TRACE0_ALPHA = 20
+};
+#define GI_PHOTON_SEED_XOR 0x5048544f4e5eed00ull
+struct Rng {
+    uint64_t hs;      // hash of (seed, stream)
+    uint32_t depth;
+};
+GI_HD Rng rng_make(uint64_t seed, uint32_t stream)
+{
+    Rng r;
+    r.hs = mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)stream + 1));
+    r.depth = 0;
+    return r;
+}
+GI_HD double rng_draw(const Rng& r, uint32_t purpose, uint32_t a = 0, uint32_t b = 0)
+{
+    uint64_t h = mix64(r.hs ^ (((uint64_t)r.depth << 32) | purpose));
+    h = mix64(h ^ (((uint64_t)a << 32) | b));
+    return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ------------------------------------------------------------------------------------------------ Halton
+GI_HD uint32_t rev_bits32(uint32_t index)
+{
+    index = (index << 16) | (index >> 16);
+    index = ((index & 0x00ff00ffu) << 8) | ((index & 0xff00ff00u) >> 8);
+    index = ((index & 0x0f0f0f0fu) << 4) | ((index & 0xf0f0f0f0u) >> 4);
+    index = ((index & 0x33333333u) << 2) | ((index & 0xccccccccu) >> 2);
+    index = ((index & 0x55555555u) << 1) | ((index & 0xaaaaaaaau) >> 1);
+    return index;
+}
+// Halton_sampler::sample: base 2 by bit reversal into the mantissa, other bases by table digit groups (Horner form of the
+// reference's sum_k table[(index / P^k) % P] * P^(n-1-k)), then one float multiply.
+GI_HD float halton_sample(const Scene& S, uint32_t dim, uint32_t index)
+{
+    if (dim == 0) {
+        union { uint32_t u; float f; } r;
+        r.u = 0x3f800000u | (rev_bits32(index) >> 9);
+        return r.f - 1.f;
+    }
+    const HaltonDim D = S.hdims[dim];
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < D.n; k++) {
+        uint32_t q = index / D.P;
+        uint32_t d = index - q * D.P;
+        sum = sum * D.P + (uint32_t)S.htable[D.off + d];
+        index = q;
+    }
+    return (float)sum * D.scale;
+}
+struct HaltonEnumD { uint32_t p2, p3, m_x, m_y, inc; float scale_x, scale_y; };
+// Halton_enum::get_index, include/halton_enum.h:106-114,136-155
+GI_HD uint32_t halton_index(const HaltonEnumD& e, uint32_t i, uint32_t x, uint32_t y)
+{
+    const unsigned long long hx = e.p2 ? (rev_bits32(x) >> (32 - e.p2)) : 0u;
+    uint32_t r3 = 0, yy = y;
+    for (uint32_t d = 0; d < e.p3; ++d) { r3 = r3 * 3 + yy % 3; yy /= 3; }
+    const unsigned long long hy = r3;
+    const uint32_t offset = (uint32_t)((hx * e.m_x + hy * e.m_y) % e.inc);
+    return offset + i * e.inc;
+}
+
+// ------------------------------------------------------------------------------------------------ samplers (include/util.h, util.cpp)
+GI_HD double fast_precise_pow(double a, double b)  // include/util.h:113-136: bit hack on the high word + exact integer power
+{
+    int e = (int)b;
+    union { double d; int32_t x[2]; } u;
+    u.d = a;
+    u.x[1] = (int32_t)((b - e) * (u.x[1] - 1072632447) + 1072632447);
+    u.x[0] = 0;
+    double r = 1.0;
+    while (e) {
+        if (e & 1) r *= a;
+        a *= a;
+        e >>= 1;
+    }
+    return r * u.d;
+}
+GI_HD V3 frame_mul(V3 n, double z, V3 r)  // the explicit 3x3 of include/util.cpp:37-42 applied to r (glm column-major)
+{
+    double k = (1.0 / (1 + z));
+    V3 c0 = v3(z + k * -n.y * -n.y, k * (n.x * -n.y), -n.x);
+    V3 c1 = v3(k * (n.x * -n.y), z + k * -n.x * -n.x, -n.y);
+    V3 c2 = v3(n.x, n.y, z);
+    return v3(c0.x * r.x + c1.x * r.y + c2.x * r.z, c0.y * r.x + c1.y * r.y + c2.y * r.z, c0.z * r.x + c1.z * r.y + c2.z * r.z);
+}
+GI_HD V3 lobe_local(float u, float v, double power, double frac, bool cap)
+{
+    float phi = (float)(v * 2.0f * GI_PI);
+    float cosTheta = cap ? (float)(frac * fast_precise_pow(1.0f - u, (1.0f / power)) + (1 - frac)) : (float)fast_precise_pow(1.0f - u, (1.0f / power));
+    float sinTheta = (float)sqrt((double)(1.0f - cosTheta * cosTheta));
+    return v3(cos((double)phi) * sinTheta, sin((double)phi) * sinTheta, cosTheta);
+}
+GI_HD V3 hemi_cos_n(V3 n, float u, float v, double power)  // include/util.cpp:35-58
+{
+    V3 res = frame_mul(n, fabs(n.z), lobe_local(u, v, power, 0, false));
+    if (n.z < 0) res.z *= -1.0;
+    return res;
+}
+GI_HD V3 sphere_cap_cos(V3 n, float u, float v, double power, double frac)  // include/util.cpp:60-83
+{
+    V3 res = frame_mul(n, fabs(n.z), lobe_local(u, v, power, frac, true));
+    if (n.z < 0) res.z *= -1.0;
+    return res;
+}
+GI_HD V3 sample_phong(V3 outdir, double power, double sx, double sy)  // include/util.cpp:91-107
+{
+    V3 out = frame_mul(outdir, fabs(outdir.z), lobe_local((float)sx, (float)sy, power, 0, false));
+    if (outdir.z < 0) out.z *= -1.0;
+    return out;
+}
+GI_HD V3 random_unit_vec(double x, double y)  // include/util.h:183-188
+{
+    double theta = acos(2 * y - 1);
+    return v3(sin(theta) * cos(2 * x * GI_PI), sin(theta) * sin(2 * x * GI_PI), cos(theta));
+}
+GI_HD V3 refr(V3 inc, V3 norm, double eta)  // include/util.h:173-181
+{
+    double d = dot(norm, inc);
+    double k = 1.0 - eta * eta * (1.0 - d * d);
+    if (k < GI_EPSILON) return reflect(inc, norm);
+    return eta * inc - (eta * d + sqrt(k)) * norm;
+}
+
+// ------------------------------------------------------------------------------------------------ boxes
+// BoundingBox::intersect(ray, 0, inf) reduced to the hit flag (t0 is only used for ordering, which the direction-ordered
+// tree provides) -- same slab arithmetic and early-outs as include/bbox.h:47-73 / :117-138.
+GI_HD bool box_hit(const double* bmin, const double* bmax, const Ray& r, double tmin, double tmax)
+{
+    {
+        double t0 = (bmin[0] - r.o.x) * r.inv.x, t1 = (bmax[0] - r.o.x) * r.inv.x;
+        if (r.inv.x < 0.0) { double t = t0; t0 = t1; t1 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    {
+        double t0 = (bmin[1] - r.o.y) * r.inv.y, t1 = (bmax[1] - r.o.y) * r.inv.y;
+        if (r.inv.y < 0.0) { double t = t0; t0 = t1; t1 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    {
+        double t0 = (bmin[2] - r.o.z) * r.inv.z, t1 = (bmax[2] - r.o.z) * r.inv.z;
+        if (r.inv.z < 0.0) { double t = t0; t0 = t1; t1 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    return true;
+}
+GI_HD bool box_contains(const double* bmin, const double* bmax, V3 p)  // include/bbox.h:41-44 (half open)
+{
+    return p.x >= bmin[0] && p.y >= bmin[1] && p.z >= bmin[2] && p.x < bmax[0] && p.y < bmax[1] && p.z < bmax[2];
+}
+// child visiting order: the reference numbers children x = bit0, z = bit1, y = bit2 (include/octree.cpp:321-328)
+GI_HD int dir_octant(const Ray& r) { return (r.d.x < 0.0 ? 1 : 0) | (r.d.z < 0.0 ? 2 : 0) | (r.d.y < 0.0 ? 4 : 0); }
+
+// ------------------------------------------------------------------------------------------------ triangle (include/entities.h:443-490)
+GI_HD bool tri_hit(const TriGeom& g, const Ray& ray, double& u, double& v, double& t)
+{
+    V3 edge1 = ld3(g.e1), edge2 = ld3(g.e2);
+    V3 p = cross(ray.d, edge2);
+    double det = dot(edge1, p);
+    if (det < GI_EPSILON && det > -GI_EPSILON) return false;
+    double inv_det = 1.0 / det;
+    V3 tvec = ray.o - ld3(g.p0);
+    u = dot(tvec, p) * inv_det;
+    if (u < 0 || u > 1) return false;
+    V3 q = cross(tvec, edge1);
+    v = dot(ray.d, q) * inv_det;
+    if (v < 0 || u + v > 1) return false;
+    t = dot(edge2, q) * inv_det;
+    if (t <= 0) return false;
+    return true;
+}
+
+struct HitRec { V3 pos; double u, v; int32_t tri; };
+
+// RayTracer::trace.  Leaves are met in the order the reference's t0-sorted list has them because each of the 8 node arrays
+// is laid out front-to-back for its direction octant; the loop stops after the first leaf that contains a new nearest hit.
+GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
+{
+    const TNode* tree = S.tnodes + (size_t)dir_octant(ray) * (size_t)S.n_node;
+    bool intersected = false, term = false;
+    double best_d2 = 0;
+    int32_t node = 0;
+    if (c) c->traces++;
+    while (node < S.n_node && !term) {
+        const TNode& nd = tree[node];
+        if (c) c->v_trace++;
+        if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, INFINITY)) { node = nd.skip; continue; }
+        if (nd.n_ref < 0) { node = node + 1; continue; }
+        const int32_t first = nd.first_ref, cnt = nd.n_ref;
+        for (int32_t k = 0; k < cnt; k++) {
+            const int32_t ti = S.leaf_refs[first + k];
+            const TriGeom& g = S.tris[ti];
+            double u, v, t;
+            if (c) c->tri++;
+            if (!tri_hit(g, ray, u, v, t)) continue;
+            if (!(g.flags & 2u)) {
+                const Mat& m = S.mats[g.mat];
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)nd.leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+            }
+            V3 hp = ray.o + t * ray.d;
+            double d2 = len2(hp - ray.o);
+            if (!intersected || d2 < best_d2) {
+                best.pos = hp; best.u = u; best.v = v; best.tri = ti;
+                best_d2 = d2;
+                intersected = true;
+                if (box_contains(nd.bmin, nd.bmax, hp)) term = true;
+            }
+        }
+        node = nd.skip;
+    }
+    return intersected;
+}
+
+// RayTracer::visible: any accepted hit with 0 < |hit-o|^2 < mt among the entities of every leaf the segment touches.
+GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
+{
+    const TNode* tree = S.tnodes + (size_t)dir_octant(ray) * (size_t)S.n_node;
+    const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
+    int32_t node = 0;
+    if (c) c->shadows++;
+    while (node < S.n_node) {
+        const TNode& nd = tree[node];
+        if (c) c->v_shadow++;
+        if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, tmax)) { node = nd.skip; continue; }
+        if (nd.n_ref < 0) { node = node + 1; continue; }
+        const int32_t first = nd.first_ref, cnt = nd.n_ref;
+        for (int32_t k = 0; k < cnt; k++) {
+            const int32_t ti = S.leaf_refs[first + k];
+            const TriGeom& g = S.tris[ti];
+            double u, v, t;
+            if (c) c->tri++;
+            if (!tri_hit(g, ray, u, v, t)) continue;
+            if (!(g.flags & 2u)) {
+                const Mat& m = S.mats[g.mat];
+                if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)nd.leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+            }
+            V3 hp = ray.o + t * ray.d;
+            double ts = len2(hp - ray.o);
+            if ((ts < mt) && (ts > 0)) return false;
+        }
+        node = nd.skip;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ photon gather
+// Lane-private max-heap of GI_GATHER_K doubles; element i of this lane lives at hp[i * stride] (LDS, bank-conflict free
+// for any per-lane i because the lane index is the fastest-varying address component).
+struct Heap { double* hp; int stride; int n; };
+GI_HD void heap_push(Heap& h, double x)
+{
+    int i = h.n++;
+    while (i > 0) {
+        int p = (i - 1) >> 1;
+        double pv = h.hp[p * h.stride];
+        if (pv >= x) break;
+        h.hp[i * h.stride] = pv;
+        i = p;
+    }
+    h.hp[i * h.stride] = x;
+}
+GI_HD void heap_replace_root(Heap& h, double x)
+{
+    int i = 0;
+    for (;;) {
+        int l = 2 * i + 1;
+        if (l >= h.n) break;
+        int cidx = l;
+        double cv = h.hp[l * h.stride];
+        if (l + 1 < h.n) {
+            double rv = h.hp[(l + 1) * h.stride];
+            if (rv > cv) { cidx = l + 1; cv = rv; }
+        }
+        if (cv <= x) break;
+        h.hp[i * h.stride] = cv;
+        i = cidx;
+    }
+    h.hp[i * h.stride] = x;
+}
+GI_HD bool boxes_touch(const double* amin, const double* amax, const double* qmin, const double* qmax)  // include/bbox.h:33-38
+{
+    return (amin[0] <= qmax[0] && amax[0] >= qmin[0]) && (amin[1] <= qmax[1] && amax[1] >= qmin[1]) && (amin[2] <= qmax[2] && amax[2] >= qmin[2]);
+}
+// RayTracer::samplePhotons(pos, dir, 32): candidates = photons of every leaf touching the (+-EPSILON) box of the leaf that
+// contains pos; the 32 nearest of them; sum col*dot(photon.dir, dir) / (pi * r32^2).  Two passes over the candidates:
+// pass 1 finds r32^2 with the heap, pass 2 accumulates everything inside it.
+GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, double* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
+{
+    V3 res = v3(0, 0, 0);
+    if (n_cand_out) *n_cand_out = 0;
+    if (c) c->gathers++;
+    if (S.n_pnode <= 0) return res;
+    // PhotonMap::Node::getBounds (include/photonMap.cpp:115-134)
+    int32_t node = 0;
+    bool found = true;
+    while (!S.pnodes[node].is_leaf) {
+        int32_t ch = node + 1;
+        int i = 0;
+        for (; i < 8; i++) {
+            const PNode& cn = S.pnodes[ch];
+            if (box_contains(cn.bmin, cn.bmax, pos)) break;
+            ch = cn.skip;
+        }
+        if (i == 8) { found = false; break; }
+        node = ch;
+    }
+    if (!found) return res;  // box of -inf: nothing is collected (root is not a leaf here)
+    double qmin[3], qmax[3];
+    {
+        const PNode& lf = S.pnodes[node];
+        for (int k = 0; k < 3; k++) { qmin[k] = lf.bmin[k] - GI_EPSILON; qmax[k] = lf.bmax[k] + GI_EPSILON; }
+    }
+    if (qmax[0] - qmin[0] <= 0) return res;  // PhotonMap::Node::get, include/photonMap.cpp:73-74
+    // pass 1
+    Heap h;
+    h.hp = heap_mem; h.stride = heap_stride; h.n = 0;
+    int ncand = 0;
+    double root = 0;
+    node = 0;
+    while (node < S.n_pnode) {
+        const PNode& nd = S.pnodes[node];
+        if (node != 0 && !boxes_touch(nd.bmin, nd.bmax, qmin, qmax)) { node = nd.skip; continue; }
+        if (!nd.is_leaf) { node = node + 1; continue; }
+        for (int32_t k = 0; k < nd.count; k++) {
+            const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
+            double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
+            if (h.n < GI_GATHER_K) { heap_push(h, d2); root = h.hp[0]; }
+            else if (d2 < root) { heap_replace_root(h, d2); root = h.hp[0]; }
+        }
+        ncand += nd.count;
+        node = nd.skip;
+    }
+    if (n_cand_out) *n_cand_out = ncand;
+    if (c) c->pcand += (unsigned long long)ncand;
+    if (ncand == 0) return res;
+    const int K = ncand < GI_GATHER_K ? ncand : GI_GATHER_K;
+    // pass 2
+    V3 s_lt = v3(0, 0, 0), s_tie = v3(0, 0, 0);
+    int c_lt = 0, c_tie = 0;
+    node = 0;
+    while (node < S.n_pnode) {
+        const PNode& nd = S.pnodes[node];
+        if (node != 0 && !boxes_touch(nd.bmin, nd.bmax, qmin, qmax)) { node = nd.skip; continue; }
+        if (!nd.is_leaf) { node = node + 1; continue; }
+        for (int32_t k = 0; k < nd.count; k++) {
+            const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
+            double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
+            if (d2 <= root) {
+                const double* dc = S.ph_dircol + (size_t)(nd.first + k) * 6;
+                V3 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
+                if (d2 < root) { s_lt = s_lt + contrib; c_lt++; }
+                else { s_tie = s_tie + contrib; c_tie++; }
+            }
+        }
+        node = nd.skip;
+    }
+    const int need = K - c_lt;  // >= 1: the heap root itself is a candidate at distance == root
+    if (c_tie <= need) res = s_lt + s_tie;
+    else res = s_lt + s_tie * ((double)need / (double)c_tie);  // equal-distance photons straddling rank 32: unspecified in the reference
+    res = res / (GI_PI * root);
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------------ shading
+// RayTracer::rayType, include/raytracer.h:481-506
+GI_HD int ray_type(const Mat& m, const Ray& ray, V3 norm, const Rng& rng)
+{
+    int type = 2;
+    if (m.roughness < .001) type = 0;
+    double opacity = 1.0 * m.opacity;
+    if (opacity < 1.0) {  // drand() in [0,1) can exceed the opacity only then
+        if (rng_draw(rng, P_TYPE_OPACITY) > opacity) {
+            double r0 = pow((1 - m.ior) / (1 + m.ior), 2.0);
+            double fs = r0 + (1 - r0) * pow(1 - dot(reflect(ray.d, norm), norm), 5.0);
+            if (rng_draw(rng, P_TYPE_FRESNEL) < fs) type = 0;
+            else type = 1;
+        }
+    }
+    return type;
+}
+// RayTracer::secondaryRay, include/raytracer.h:321-379
+GI_HD void secondary_ray(const Ray& ray, const Mat& m, V3& norm, double sx, double sy, V3& refDir, V3& f, double& roughness, V3& contrib, double& offset, const Rng& rng)
+{
+    bool backface = false;
+    if (dot(norm, ray.d) > 0) { norm = norm * -1.0; backface = true; }
+    V3 color = ld3(m.diffuse);
+    roughness = m.roughness;
+    int type = ray_type(m, ray, norm, rng);
+    if (type == 1) {
+        refDir = backface ? refr(ray.d, norm, m.ior) : refr(ray.d, norm, 1.0 / m.ior);
+        offset *= -1;
+        contrib = v3(1, 1, 1);
+        f = 1.0 * color;
+    } else if (type == 0) {
+        refDir = reflect(ray.d, norm);
+        contrib = v3(1, 1, 1);
+        f = 1.0 * color;
+    } else {
+        if (m.roughness < .9) {
+            refDir = sample_phong(reflect(ray.d, norm), (1.0 / (m.roughness)) + 1, sx, sy);
+            if (dot(refDir, norm) < 0) refDir = reflect(refDir, norm);
+        } else
+            refDir = hemi_cos_n(norm, (float)sx, (float)sy, 2);
+        f = 1.0 * color;
+        V3 inf = color;
+        contrib = contrib * inf;
+        contrib = mix(contrib, inf, 0.5);
+    }
+}
+GI_HD V3 shading_normal(const Scene& S, const HitRec& h)  // include/entities.h:478-485
+{
+    const TriShade& sh = S.shade[h.tri];
+    if (S.tris[h.tri].flags & 1u) return (1 - h.u - h.v) * ld3(sh.n0) + h.u * ld3(sh.n1) + h.v * ld3(sh.n2);
+    return ld3(sh.fnorm);
+}
+
+// One path: RayTracer::radiance(ray, 0, ..., sample, (1,1,1)) as a loop.  L = A_0 + f_0 (A_1 + f_1 (A_2 + ...)) is
+// accumulated as sum_k (prod_{j<k} f_j) A_k with A = color*i + emissive + color*caustic on continue, color*i on a failed
+// roulette, ambient on a miss and 0 past MAX_DEPTH.
+GI_HD V3 radiance_path(const Scene& S, Ray ray, uint32_t sample, uint64_t seed, double* heap_mem, int heap_stride, Counters* c)
+{
+    Rng rng = rng_make(seed, sample);
+    V3 L = v3(0, 0, 0), T = v3(1, 1, 1), contrib = v3(1, 1, 1);
+    for (int depth = 0; depth <= GI_MAX_DEPTH; depth++) {
+        rng.depth = (uint32_t)depth;
+        HitRec h;
+        if (!trace(S, ray, rng, P_TRACE_ALPHA, h, c)) { L = L + T * ld3(S.ambient); break; }
+        if (c) c->shaded++;
+        float sx = halton_sample(S, 2 + 2 * depth, sample);
+        float sy = halton_sample(S, 3 + 2 * depth, sample);
+        const Mat& m = S.mats[S.tris[h.tri].mat];
+        V3 norm = shading_normal(S, h);
+        V3 color = ld3(m.diffuse);
+        V3 refDir, f = v3(1, 1, 1), i = v3(0, 0, 0);
+        double roughness, offset = GI_SHADOW_BIAS;
+        secondary_ray(ray, m, norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
+        for (int li = 0; li < S.n_light; li++) {
+            const LightD& lt = S.lights[li];
+            double ry = rng_draw(rng, P_LIGHT_Y | ((uint32_t)li << 8));
+            double rx = rng_draw(rng, P_LIGHT_X | ((uint32_t)li << 8));
+            V3 lpos = ld3(lt.pos);
+            V3 so = h.pos + GI_SHADOW_BIAS * norm;
+            V3 lightDir = (lpos + lt.rad * random_unit_vec(rx, ry)) - so;
+            double maxt = len2(lightDir);
+            double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
+            Ray sray = make_ray(so, lightDir);
+            if (visible(S, sray, maxt, rng, (uint32_t)li, c)) {
+                double d = dot(norm, normalize(lpos - h.pos));
+                if (d < 0) d = 0;
+                double l = pow(d, (1.0 / roughness));
+                i = ld3(lt.col) * l * hfrac;
+            }
+        }
+        V3 caustic = depth <= 10 ? gather(S, h.pos, refDir, heap_mem, heap_stride, nullptr, c) : v3(0, 0, 0);
+        double q = comp_max(contrib);
+        if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
+            f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
+            L = L + T * (color * i + ld3(m.emissive) + color * caustic);
+            T = T * f;
+            ray = make_ray(h.pos + offset * norm, refDir);
+        } else {
+            L = L + T * (color * i);
+            break;
+        }
+    }
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------ camera / pixel loop
+struct Frame {
+    V3 cam_pos, cam_up, screen_center, right;
+    double sw, sh;
+    int32_t w, h;
+    HaltonEnumD he;
+    int32_t min_samples, max_samples;
+    double noise_thresh;
+    uint64_t seed;
+    int32_t stripe_h, stripe_rank, stripe_world, local_rows;
+};
+// primary ray of sample s of pixel (x,y): include/raytracer.h:112-129 (FOCAL_BLUR == 0)
+GI_HD Ray primary_ray(const Scene& S, const Frame& F, int s, int x, int y, uint32_t& idx)
+{
+    idx = halton_index(F.he, (uint32_t)s, (uint32_t)x, (uint32_t)y);
+    double xr = halton_sample(S, 0, idx);
+    double yr = halton_sample(S, 1, idx);
+    double dx = (float)((float)xr * F.he.scale_x);
+    double dy = (float)((float)yr * F.he.scale_y);
+    V3 pixelPos = F.screen_center + (F.sw * (dx / F.w - .5)) * F.right - (F.sh * (dy / F.h - .5)) * F.cam_up;
+    V3 eyePos = F.cam_pos;
+    return make_ray(eyePos, normalize(pixelPos - eyePos));
+}
+// adaptive per-pixel loop state: include/raytracer.h:102-148
+struct PixelState { V3 color, lastCol; double var; int samps, s; };
+GI_HD void pixel_begin(PixelState& p) { p.color = v3(0.5, 0.5, 0.5); p.lastCol = v3(0, 0, 0); p.var = 0; p.samps = 0; p.s = 0; }
+GI_HD bool pixel_wants_sample(const PixelState& p, const Frame& F) { return p.s < F.max_samples && p.samps < F.min_samples; }
+GI_HD void pixel_add_sample(PixelState& p, const Frame& F, V3 L)
+{
+    p.lastCol = p.color;
+    if (p.s == 0) p.color = L;
+    else p.color = (1.0 * p.s * p.color + L) * (1.0 / (p.s + 1));
+    if (p.s > 0) p.var = (1.0 * 5 * p.var + length(p.color - p.lastCol)) * (1.0 / (5 + 1));
+    if (p.s > 0 && p.var > F.noise_thresh) p.samps -= 2;
+    p.s++;
+    p.samps++;
+}
+// local row r of this rank -> frame row (interleaved stripes)
+GI_HD int global_row(const Frame& F, int r) { return ((r / F.stripe_h) * F.stripe_world + F.stripe_rank) * F.stripe_h + r % F.stripe_h; }
+
+// ------------------------------------------------------------------------------------------------ photon emission (tracePhotons)
+struct PhotonOut { double v[9]; };
+// one (photon index i, light li): up to 500 emission tries; returns true and fills out when a caustic photon is stored
+GI_HD bool emit_photon(const Scene& S, int32_t i, int32_t li, int32_t count, int32_t max_depth, uint64_t seed, PhotonOut& out, int32_t& tries_out)
+{
+    const LightD& l = S.lights[li];
+    Rng rng = rng_make(seed ^ GI_PHOTON_SEED_XOR, (uint32_t)i * (uint32_t)S.n_light + (uint32_t)li);
+    int tries = 0;
+    bool stored = false;
+    V3 lpos = ld3(l.pos);
+    while (!stored && tries < 500) {
+        rng.depth = (uint32_t)tries * 16u;
+        float sx = halton_sample(S, 0, (uint32_t)(i * 500 + tries));
+        float sy = halton_sample(S, 1, (uint32_t)(i * 500 + tries));
+        // Light::getPointInRange, include/light.h:47-53
+        V3 pos = l.angle < 1 ? lpos + l.rad * sphere_cap_cos(ld3(l.dir), sx, sy, 1, l.angle) : lpos + l.rad * random_unit_vec(sx, sy);
+        double d13 = rng_draw(rng, P_PH_DIR_V);
+        double d5 = rng_draw(rng, P_PH_DIR_U);
+        V3 dir = sphere_cap_cos(normalize(pos - lpos), (float)fmod(d5 + 5 * i, 1.0), (float)fmod(d13 + 13 * i, 1.0), 2, l.angle);
+        Ray r = make_ray(pos, dir);
+        V3 col = (1.0 / count) * .5 * l.angle * ld3(l.col);
+        HitRec h;
+        int depth = 0;
+        bool term = false, isCaustic = false;
+        if (!trace(S, r, rng, P_PH_TRACE0_ALPHA, h, nullptr)) { tries++; continue; }
+        int32_t current = h.tri;
+        V3 hit = h.pos;
+        while (depth < max_depth && !term) {
+            rng.depth = (uint32_t)tries * 16u + (uint32_t)depth + 1u;
+            double roughness = S.mats[S.tris[current].mat].roughness;
+            if (roughness < 0.1) {
+                if (!trace(S, r, rng, P_TRACE_ALPHA, h, nullptr)) { term = true; continue; }
+                current = h.tri;
+                hit = h.pos;
+                const Mat& m = S.mats[S.tris[current].mat];
+                V3 norm = shading_normal(S, h);
+                V3 refDir, f, contrib = v3(0, 0, 0);
+                double offset = GI_SHADOW_BIAS;
+                double e13 = rng_draw(rng, P_PH_SEC_V);
+                double e5 = rng_draw(rng, P_PH_SEC_U);
+                secondary_ray(r, m, norm, fmod(e5 + 5 * i, 1.0), fmod(e13 + 13 * i, 1.0), refDir, f, roughness, contrib, offset, rng);
+                col = col * f;
+                r = make_ray(hit + offset * norm, refDir);
+                isCaustic = true;
+            }
+            if (depth > 0 && isCaustic && roughness >= 0.1) {
+                out.v[0] = hit.x; out.v[1] = hit.y; out.v[2] = hit.z;
+                out.v[3] = r.d.x; out.v[4] = r.d.y; out.v[5] = r.d.z;
+                out.v[6] = col.x; out.v[7] = col.y; out.v[8] = col.z;
+                term = true;
+                stored = true;
+            }
+            depth++;
+        }
+        tries++;
+    }
+    tries_out = tries;
+    return stored;
+}
+
+}  // namespace gi

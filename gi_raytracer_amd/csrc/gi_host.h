@@ -1,0 +1,60 @@
+/* gi_host.h -- host-side feeders of the hot path (C API): scene ingestion, Octree::rebuild, PhotonMap::rebuild and the
+ * flattening into the gi_scene_desc / gi_photon_map_desc tables that include/gi_hip.h consumes.
+ *
+ * These are the "callers and data formats either side of the path" (SURVEY.md 8 f2/f3).  They run on the host exactly
+ * as in the reference (its loaders and tree builders are host code too); all per-ray / per-pixel work is in the HIP
+ * kernels.  The C++ classes of include/gi/ (Octree, PhotonMap, RayTracer ...) are built on this API; Python reaches it
+ * through ctypes (gi_raytracer_amd/__init__.py).
+ */
+#ifndef GI_HOST_H
+#define GI_HOST_H
+#include <stdint.h>
+#include "../../include/gi_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gih_scene gih_scene;
+
+gih_scene* gih_scene_create(void);
+void gih_scene_destroy(gih_scene*);
+const char* gih_last_error(const gih_scene*);
+
+/* replaces loadScene + loadOBJ (include/sceneLoader.cpp:12-185, include/meshLoader.cpp:18-99): same keyword set and the
+ * same word-wise tokenising; vertices, normals and uvs are rounded to float as the reference's loader does.  A `mat` line
+ * without its 5th number gets IOR 1.0 (the reference leaves it uninitialised).  Missing mesh files are skipped.
+ * Returns 0, or -1 when the .scn itself cannot be opened.                                                            */
+int gih_load_scn(gih_scene*, const char* path);
+
+/* programmatic construction = Octree::push_back (include/octree.cpp:25-50) */
+int gih_add_material(gih_scene*, const double* mat9);                 /* returns the material index */
+int gih_add_triangles(gih_scene*, int32_t n, const double* pos, const double* nrm, const double* uv, const int32_t* mat_idx);
+int gih_add_light(gih_scene*, const double* pos3, const double* col3, double rad);
+int gih_set_ambient(gih_scene*, const double* rgb3);
+
+/* render settings a .scn may carry (include/raytracer.h:721-726, include/sceneLoader.cpp:160-179) */
+typedef struct gih_settings {
+    int32_t photons, photon_depth, min_samples, max_samples;
+    double noise_thresh;
+    double ambient[3];
+    double cam_pos[3], cam_up[3], cam_forward[3], sensor_diag, focal_dist;
+} gih_settings;
+int gih_get_settings(const gih_scene*, gih_settings* out);
+/* Camera(pos, lookAt) / Camera::setDir (include/camera.h:9-23) */
+int gih_set_camera(gih_scene*, const double* pos3, const double* look_at3);
+
+/* replaces Octree::rebuild (include/octree.cpp:53-119): light cone precompute + Octree::Node::partition (:316-384) */
+int gih_build_octree(gih_scene*);
+/* pointers stay valid until the scene is modified or destroyed */
+int gih_get_scene_desc(const gih_scene*, gi_scene_desc* out);
+int gih_counts(const gih_scene*, int32_t* n_tri, int32_t* n_mat, int32_t* n_light, int32_t* n_node, int32_t* n_ref);
+
+/* replaces PhotonMap::push_back + rebuild (include/photonMap.cpp:24-47,137-192) over the scene's root box
+ * (RayTracer::setScene, include/raytracer.h:38); photons [n][9] are copied                                           */
+int gih_build_photon_map(gih_scene*, int32_t n, const double* photons);
+int gih_get_photon_desc(const gih_scene*, gi_photon_map_desc* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

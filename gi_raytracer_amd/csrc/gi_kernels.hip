@@ -1,0 +1,531 @@
+// gi_kernels.hip -- gfx950 kernels + the C ABI of include/gi_hip.h.
+//
+// Kernels (all one ray / one pixel per lane, 64-wide waves, scene tables read through L1/L2):
+//   k_render     the pixel loop of RayTracer::run with the whole path inside (include/raytracer.h:93-160,167-579)
+//   k_trace / k_visible / k_gather / k_radiance   function-level entry points (parity tests, public C++ methods)
+//   k_emit       RayTracer::tracePhotons (include/raytracer.h:582-715), one (photon index, light) per lane
+// Host side of this file: device layouts (8 direction-ordered copies of the octree, leaf-ordered photons, Halton tables)
+// and the gi_* entry points.  No CPU fallback exists: every entry needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gi_hip.h"
+#include "gi_device.h"
+#include "gi_layout.h"
+
+using namespace gi;
+
+#define GI_BLOCK 256
+
+// ================================================================================================= kernels
+template <bool COUNT>
+__global__ __launch_bounds__(GI_BLOCK) void k_render(Scene S, Frame F, void* out, int out_f64, int32_t* out_spp,
+                                                     unsigned int* tile_counter, Counters* counters)
+{
+    __shared__ double heap[GI_GATHER_K * GI_BLOCK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tiles_x = (F.w + 7) >> 3, tiles_y = (F.local_rows + 7) >> 3;
+    const unsigned int n_tiles = (unsigned int)(tiles_x * tiles_y);
+    Counters cnt;
+    if (COUNT) memset(&cnt, 0, sizeof cnt);
+    for (;;) {
+        unsigned int t0 = 0;
+        if (lane == 0) t0 = atomicAdd(tile_counter, 1u);   // one tile of 8x8 pixels per wave, dealt dynamically
+        const unsigned int tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)t0);
+        if (tile >= n_tiles) break;
+        const int tx = (int)(tile % (unsigned)tiles_x), ty = (int)(tile / (unsigned)tiles_x);
+        const int x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+        if (x < F.w && ly < F.local_rows) {
+            const int y = global_row(F, ly);
+            PixelState ps;
+            pixel_begin(ps);
+            while (pixel_wants_sample(ps, F)) {
+                uint32_t idx;
+                Ray ray = primary_ray(S, F, ps.s, x, y, idx);
+                V3 L = radiance_path(S, ray, idx, F.seed, heap + tid, GI_BLOCK, COUNT ? &cnt : nullptr);
+                pixel_add_sample(ps, F, L);
+            }
+            const size_t o = ((size_t)ly * F.w + x);
+            if (out_f64) {
+                double* p = (double*)out + o * 3;
+                p[0] = ps.color.x; p[1] = ps.color.y; p[2] = ps.color.z;
+            } else {
+                float* p = (float*)out + o * 3;
+                p[0] = (float)ps.color.x; p[1] = (float)ps.color.y; p[2] = (float)ps.color.z;
+            }
+            if (out_spp) out_spp[o] = ps.s;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters->v_trace, cnt.v_trace); atomicAdd(&counters->v_shadow, cnt.v_shadow);
+        atomicAdd(&counters->tri, cnt.tri); atomicAdd(&counters->shaded, cnt.shaded);
+        atomicAdd(&counters->pcand, cnt.pcand); atomicAdd(&counters->traces, cnt.traces);
+        atomicAdd(&counters->shadows, cnt.shadows); atomicAdd(&counters->gathers, cnt.gathers);
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_trace(Scene S, int n, const double* rays, int32_t* hit, int32_t* ent, double* res)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rays + (size_t)i * 6;
+    Ray ray = make_ray_exact(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]));
+    Rng rng = rng_make(0, (uint32_t)i);
+    HitRec h;
+    bool ok = trace(S, ray, rng, P_TRACE_ALPHA, h, nullptr);
+    hit[i] = ok ? 1 : 0;
+    ent[i] = ok ? h.tri : -1;
+    double* o = res + (size_t)i * 8;
+    if (ok) {
+        V3 nn = shading_normal(S, h);
+        o[0] = h.pos.x; o[1] = h.pos.y; o[2] = h.pos.z; o[3] = nn.x; o[4] = nn.y; o[5] = nn.z; o[6] = h.u; o[7] = h.v;
+    } else
+        for (int k = 0; k < 8; k++) o[k] = 0;
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_visible(Scene S, int n, const double* q, int32_t* vis)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = q + (size_t)i * 6;
+    V3 o = v3(p[0], p[1], p[2]), t = v3(p[3], p[4], p[5]);
+    V3 ld = t - o;
+    double maxt = len2(ld);
+    Ray sr = make_ray(o, ld);
+    Rng rng = rng_make(0, (uint32_t)i);
+    vis[i] = visible(S, sr, maxt, rng, 0, nullptr) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_gather(Scene S, int n, const double* q, double* res3, int32_t* n_cand)
+{
+    __shared__ double heap[GI_GATHER_K * GI_BLOCK];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = q + (size_t)i * 6;
+    int nc = 0;
+    V3 r = gather(S, v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5]), heap + threadIdx.x, GI_BLOCK, &nc, nullptr);
+    res3[(size_t)i * 3] = r.x; res3[(size_t)i * 3 + 1] = r.y; res3[(size_t)i * 3 + 2] = r.z;
+    if (n_cand) n_cand[i] = nc;
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_radiance(Scene S, int n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3)
+{
+    __shared__ double heap[GI_GATHER_K * GI_BLOCK];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rays + (size_t)i * 6;
+    Ray ray = make_ray_exact(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]));
+    V3 L = radiance_path(S, ray, stream[i], seed, heap + threadIdx.x, GI_BLOCK, nullptr);
+    out3[(size_t)i * 3] = L.x; out3[(size_t)i * 3 + 1] = L.y; out3[(size_t)i * 3 + 2] = L.z;
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_emit(Scene S, int count, int max_depth, uint64_t seed, PhotonOut* out, int32_t* stored, int32_t* tries)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count * S.n_light) return;
+    int i = j / S.n_light, li = j % S.n_light;
+    PhotonOut po;
+    int32_t t = 0;
+    bool ok = emit_photon(S, i, li, count, max_depth, seed, po, t);
+    stored[j] = ok ? 1 : 0;
+    tries[j] = t;
+    if (ok) out[j] = po;
+}
+
+__global__ void k_halton(Scene S, int n, const uint32_t* dim, const uint32_t* index, float* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = halton_sample(S, dim[i], index[i]);
+}
+__global__ void k_halton_index(HaltonEnumD he, int n, const uint32_t* sxy, uint32_t* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = halton_index(he, sxy[i * 3], sxy[i * 3 + 1], sxy[i * 3 + 2]);
+}
+
+// ================================================================================================= host side
+namespace {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t upload(const std::vector<T>& v)
+    {
+        release();
+        n = v.size();
+        size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        hipError_t e = hipMalloc((void**)&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        if (n) e = hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e != hipSuccess) p = nullptr;
+        return e;
+    }
+};
+
+}  // namespace
+
+struct gi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_scene = false;
+    Scene S{};
+    DevBuf<TNode> d_tnodes;
+    DevBuf<int32_t> d_refs;
+    DevBuf<TriGeom> d_tris;
+    DevBuf<TriShade> d_shade;
+    DevBuf<Mat> d_mats;
+    DevBuf<LightD> d_lights;
+    DevBuf<PNode> d_pnodes;
+    DevBuf<double> d_ph_pos, d_ph_dircol;
+    DevBuf<HaltonDim> d_hdims;
+    DevBuf<uint16_t> d_htable;
+    DevBuf<unsigned int> d_tile_counter;
+    DevBuf<Counters> d_counters;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0;
+    int last_launches = 0;
+    bool count_enabled = false;
+    Counters last_counters{};
+    int n_cu = 256;
+};
+
+namespace {
+
+int fail(gi_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess) return fail((c), GI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int gi_create(gi_ctx** out, int device_ordinal)
+{
+    if (!out) return GI_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GI_E_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return GI_E_INVALID;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return GI_E_NO_DEVICE;
+    gi_ctx* c = new gi_ctx();
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    std::vector<HaltonDim> dims;
+    std::vector<uint16_t> table;
+    build_halton_tables(dims, table);
+    if (c->d_hdims.upload(dims) != hipSuccess || c->d_htable.upload(table) != hipSuccess || c->d_tile_counter.alloc(1) != hipSuccess ||
+        c->d_counters.alloc(1) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return GI_E_HIP;
+    }
+    c->S.hdims = c->d_hdims.p;
+    c->S.htable = c->d_htable.p;
+    *out = c;
+    return GI_OK;
+}
+
+void gi_destroy(gi_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+const char* gi_last_error(const gi_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int gi_set_stream(gi_ctx* c, void* s)
+{
+    if (!c) return GI_E_INVALID;
+    c->stream = (hipStream_t)s;
+    return GI_OK;
+}
+
+int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
+{
+    if (!c) return GI_E_INVALID;
+    HostScene H;
+    std::string err;
+    if (!layout_scene(d, H, err)) return fail(c, GI_E_INVALID, err);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->d_tnodes.upload(H.tnodes));
+    HIP_TRY(c, c->d_refs.upload(H.refs));
+    HIP_TRY(c, c->d_tris.upload(H.tris));
+    HIP_TRY(c, c->d_shade.upload(H.shade));
+    HIP_TRY(c, c->d_mats.upload(H.mats));
+    HIP_TRY(c, c->d_lights.upload(H.lights));
+    Scene& S = c->S;
+    S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
+    S.mats = c->d_mats.p; S.lights = c->d_lights.p;
+    S.n_node = H.n_node; S.n_tri = H.n_tri; S.n_light = H.n_light;
+    for (int k = 0; k < 3; k++) S.ambient[k] = H.ambient[k];
+    // a new scene invalidates the photon map (RayTracer::setScene allocates a fresh PhotonMap, include/raytracer.h:38)
+    S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0;
+    c->have_scene = true;
+    return GI_OK;
+}
+
+int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
+{
+    if (!c || !d) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "upload_photons: no scene");
+    HostPhotons H;
+    std::string err;
+    if (!layout_photons(d, H, err)) return fail(c, GI_E_INVALID, err);
+    HIP_TRY(c, hipSetDevice(c->device));
+    Scene& S = c->S;
+    if (H.n_node == 0) {
+        S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0;
+        return GI_OK;
+    }
+    HIP_TRY(c, c->d_pnodes.upload(H.nodes));
+    HIP_TRY(c, c->d_ph_pos.upload(H.pos));
+    HIP_TRY(c, c->d_ph_dircol.upload(H.dircol));
+    S.pnodes = c->d_pnodes.p; S.ph_pos = c->d_ph_pos.p; S.ph_dircol = c->d_ph_dircol.p;
+    S.n_pnode = H.n_node; S.n_photon = H.n_photon;
+    return GI_OK;
+}
+
+int gi_local_rows(const gi_render_params* p) { return local_rows(p); }
+
+int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
+{
+    if (!c || !d_out) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "render: no scene uploaded");
+    Frame F;
+    std::string ferr;
+    if (!make_frame(p, F, ferr)) return fail(c, GI_E_INVALID, ferr);
+    if (cancel && *cancel) return fail(c, GI_E_CANCELLED, "render: cancelled");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->last_ms = 0; c->last_launches = 0;
+    if (F.local_rows == 0) return GI_OK;
+    HIP_TRY(c, hipMemsetAsync(c->d_tile_counter.p, 0, sizeof(unsigned int), c->stream));
+    if (c->count_enabled) HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
+    const int grid = c->n_cu * 2;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (c->count_enabled)
+        hipLaunchKernelGGL(k_render<true>, dim3(grid), dim3(GI_BLOCK), 0, c->stream, c->S, F, d_out, out_is_f64, d_spp, c->d_tile_counter.p, c->d_counters.p);
+    else
+        hipLaunchKernelGGL(k_render<false>, dim3(grid), dim3(GI_BLOCK), 0, c->stream, c->S, F, d_out, out_is_f64, d_spp, c->d_tile_counter.p, c->d_counters.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->last_launches = 1;
+    return GI_OK;
+}
+
+int gi_last_render_ms(gi_ctx* c, float* ms, int32_t* n_launches)
+{
+    if (!c) return GI_E_INVALID;
+    if (c->last_launches > 0) {
+        HIP_TRY(c, hipEventSynchronize(c->ev1));
+        HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    }
+    if (ms) *ms = c->last_ms;
+    if (n_launches) *n_launches = c->last_launches;
+    return GI_OK;
+}
+
+int gi_set_counters(gi_ctx* c, int enable) { if (!c) return GI_E_INVALID; c->count_enabled = enable != 0; return GI_OK; }
+int gi_get_counters(gi_ctx* c, int64_t* out8)
+{
+    if (!c || !out8) return GI_E_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Counters h;
+    HIP_TRY(c, hipMemcpy(&h, c->d_counters.p, sizeof h, hipMemcpyDeviceToHost));
+    out8[0] = (int64_t)h.v_trace; out8[1] = (int64_t)h.v_shadow; out8[2] = (int64_t)h.tri; out8[3] = (int64_t)h.shaded;
+    out8[4] = (int64_t)h.pcand; out8[5] = (int64_t)h.traces; out8[6] = (int64_t)h.shadows; out8[7] = (int64_t)h.gathers;
+    return GI_OK;
+}
+
+int gi_render_host(gi_ctx* c, const gi_render_params* p, void* h_out, int out_is_f64, int32_t* h_spp, volatile const int* cancel)
+{
+    if (!c || !h_out || !p) return GI_E_INVALID;
+    const size_t npix = (size_t)gi_local_rows(p) * (size_t)std::max(p->width, 0);
+    if (npix == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = npix * 3 * (out_is_f64 ? 8 : 4);
+    void* d_out = nullptr;
+    int32_t* d_spp = nullptr;
+    HIP_TRY(c, hipMalloc(&d_out, bytes));
+    if (h_spp && hipMalloc((void**)&d_spp, npix * 4) != hipSuccess) { (void)hipFree(d_out); return fail(c, GI_E_HIP, "hipMalloc spp"); }
+    int rc = gi_render_device(c, p, d_out, out_is_f64, d_spp, cancel);
+    if (rc == GI_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && h_spp) e = hipMemcpy(h_spp, d_spp, npix * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, GI_E_HIP, std::string("render_host: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_out);
+    if (d_spp) (void)hipFree(d_spp);
+    return rc;
+}
+
+// ---- function-level entries: host in, host out
+#define GI_GRID(n) dim3((unsigned)(((n) + GI_BLOCK - 1) / GI_BLOCK)), dim3(GI_BLOCK)
+
+int gi_trace(gi_ctx* c, int32_t n, const double* rays, int32_t* hit, int32_t* ent, double* res)
+{
+    if (!c || n < 0 || (n && (!rays || !hit || !ent || !res))) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "trace: no scene uploaded");
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_r, d_o;
+    DevBuf<int32_t> d_h, d_e;
+    HIP_TRY(c, d_r.upload(std::vector<double>(rays, rays + (size_t)n * 6)));
+    HIP_TRY(c, d_o.alloc((size_t)n * 8)); HIP_TRY(c, d_h.alloc(n)); HIP_TRY(c, d_e.alloc(n));
+    hipLaunchKernelGGL(k_trace, GI_GRID(n), 0, c->stream, c->S, n, d_r.p, d_h.p, d_e.p, d_o.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(hit, d_h.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ent, d_e.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(res, d_o.p, (size_t)n * 64, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_visible(gi_ctx* c, int32_t n, const double* q, int32_t* vis)
+{
+    if (!c || n < 0 || (n && (!q || !vis))) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "visible: no scene uploaded");
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_q;
+    DevBuf<int32_t> d_v;
+    HIP_TRY(c, d_q.upload(std::vector<double>(q, q + (size_t)n * 6)));
+    HIP_TRY(c, d_v.alloc(n));
+    hipLaunchKernelGGL(k_visible, GI_GRID(n), 0, c->stream, c->S, n, d_q.p, d_v.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(vis, d_v.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_gather(gi_ctx* c, int32_t n, const double* q, double* res3, int32_t* n_cand)
+{
+    if (!c || n < 0 || (n && (!q || !res3))) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "gather: no scene uploaded");
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_q, d_r;
+    DevBuf<int32_t> d_n;
+    HIP_TRY(c, d_q.upload(std::vector<double>(q, q + (size_t)n * 6)));
+    HIP_TRY(c, d_r.alloc((size_t)n * 3)); HIP_TRY(c, d_n.alloc(n));
+    hipLaunchKernelGGL(k_gather, GI_GRID(n), 0, c->stream, c->S, n, d_q.p, d_r.p, d_n.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(res3, d_r.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (n_cand) HIP_TRY(c, hipMemcpy(n_cand, d_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_radiance(gi_ctx* c, int32_t n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3)
+{
+    if (!c || n < 0 || (n && (!rays || !stream || !out3))) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "radiance: no scene uploaded");
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_r, d_o;
+    DevBuf<uint32_t> d_s;
+    HIP_TRY(c, d_r.upload(std::vector<double>(rays, rays + (size_t)n * 6)));
+    HIP_TRY(c, d_s.upload(std::vector<uint32_t>(stream, stream + n)));
+    HIP_TRY(c, d_o.alloc((size_t)n * 3));
+    hipLaunchKernelGGL(k_radiance, GI_GRID(n), 0, c->stream, c->S, n, d_r.p, d_s.p, seed, d_o.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out3, d_o.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_emit_photons(gi_ctx* c, int32_t count, int32_t max_depth, uint64_t seed, double* photons_out, int32_t cap, int64_t* tries_out)
+{
+    if (!c || count < 0 || cap < 0 || (cap && !photons_out)) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "emit_photons: no scene uploaded");
+    const long long total = (long long)count * c->S.n_light;
+    if (tries_out) *tries_out = 0;
+    if (total == 0) return 0;
+    if (total > 0x7fffffffLL) return fail(c, GI_E_INVALID, "emit_photons: count too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<PhotonOut> d_p;
+    DevBuf<int32_t> d_s, d_t;
+    HIP_TRY(c, d_p.alloc((size_t)total)); HIP_TRY(c, d_s.alloc((size_t)total)); HIP_TRY(c, d_t.alloc((size_t)total));
+    hipLaunchKernelGGL(k_emit, GI_GRID(total), 0, c->stream, c->S, count, max_depth, seed, d_p.p, d_s.p, d_t.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<PhotonOut> hp((size_t)total);
+    std::vector<int32_t> hs((size_t)total), ht((size_t)total);
+    HIP_TRY(c, hipMemcpy(hp.data(), d_p.p, (size_t)total * sizeof(PhotonOut), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hs.data(), d_s.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(ht.data(), d_t.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    // compaction in (photon index, light) order = the order one reference thread appends them (include/raytracer.h:593-706)
+    int stored = 0;
+    int64_t tries = 0;
+    for (long long j = 0; j < total; j++) {
+        tries += ht[(size_t)j];
+        if (!hs[(size_t)j]) continue;
+        if (stored < cap) memcpy(photons_out + (size_t)stored * 9, hp[(size_t)j].v, 72);
+        stored++;
+    }
+    if (tries_out) *tries_out = tries;
+    if (stored > cap) return fail(c, GI_E_INVALID, "emit_photons: output capacity too small");
+    return stored;
+}
+
+int gi_halton_sample(gi_ctx* c, int32_t n, const uint32_t* dim, const uint32_t* index, float* out)
+{
+    if (!c || n < 0 || (n && (!dim || !index || !out))) return GI_E_INVALID;
+    if (n == 0) return GI_OK;
+    for (int i = 0; i < n; i++) if (dim[i] > 255) return fail(c, GI_E_INVALID, "halton_sample: dimension > 255");
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<uint32_t> d_d, d_i;
+    DevBuf<float> d_o;
+    HIP_TRY(c, d_d.upload(std::vector<uint32_t>(dim, dim + n)));
+    HIP_TRY(c, d_i.upload(std::vector<uint32_t>(index, index + n)));
+    HIP_TRY(c, d_o.alloc(n));
+    hipLaunchKernelGGL(k_halton, GI_GRID(n), 0, c->stream, c->S, n, d_d.p, d_i.p, d_o.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, d_o.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_halton_index(gi_ctx* c, int32_t width, int32_t height, int32_t n, const uint32_t* sxy, uint32_t* out)
+{
+    if (!c || width <= 0 || height <= 0 || n < 0 || (n && (!sxy || !out))) return GI_E_INVALID;
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<uint32_t> d_i, d_o;
+    HIP_TRY(c, d_i.upload(std::vector<uint32_t>(sxy, sxy + (size_t)n * 3)));
+    HIP_TRY(c, d_o.alloc(n));
+    hipLaunchKernelGGL(k_halton_index, GI_GRID(n), 0, c->stream, make_halton_enum((unsigned)width, (unsigned)height), n, d_i.p, d_o.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, d_o.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// gi_layout.h -- host-side construction of the device tables (pure C++, no HIP calls).
+//
+// Turns the flat C-ABI descriptions (include/gi_hip.h) into the arrays the kernels read (gi_device.h):
+//   * 8 direction-ordered pre-order copies of the scene octree with skip links (stackless front-to-back traversal),
+//   * per-triangle test record {p0, e1, e2, material, flags} and shading record,
+//   * photon octree in pre-order with skip links and photons re-ordered leaf by leaf,
+//   * Halton/Faure digit-group tables and the per-frame Halton enumeration constants.
+// Used by gi_kernels.hip (which uploads the vectors) and by tests/host_emul (which points a gi::Scene at them).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/gi_hip.h"
+#include "gi_device.h"
+
+namespace gi {
+
+struct HostScene {
+    std::vector<TNode> tnodes;
+    std::vector<int32_t> refs;
+    std::vector<TriGeom> tris;
+    std::vector<TriShade> shade;
+    std::vector<Mat> mats;
+    std::vector<LightD> lights;
+    int32_t n_node = 0, n_tri = 0, n_light = 0;
+    double ambient[3] = {0, 0, 0};
+};
+struct HostPhotons {
+    std::vector<PNode> nodes;
+    std::vector<double> pos, dircol;
+    int32_t n_node = 0, n_photon = 0;
+};
+
+// Faure permutations and per-base digit-group tables of Halton_sampler (include/halton_sampler.h:573-603,890-1414).
+inline void build_halton_tables(std::vector<HaltonDim>& dims, std::vector<uint16_t>& table)
+{
+    const unsigned max_base = 1619u;
+    std::vector<std::vector<uint16_t>> perm(max_base + 1);
+    for (unsigned k = 1; k <= 3; ++k) { perm[k].resize(k); for (unsigned i = 0; i < k; ++i) perm[k][i] = (uint16_t)i; }
+    for (unsigned base = 4; base <= max_base; ++base) {
+        std::vector<uint16_t>& pb = perm[base];
+        pb.resize(base);
+        const unsigned half = base / 2;
+        if (base & 1) {
+            const std::vector<uint16_t>& prev = perm[base - 1];
+            for (unsigned i = 0; i + 1 < base; ++i) pb[i + (i >= half)] = (uint16_t)(prev[i] + (prev[i] >= half));
+            pb[half] = (uint16_t)half;
+        } else {
+            const std::vector<uint16_t>& hp = perm[half];
+            for (unsigned i = 0; i < half; ++i) { pb[i] = (uint16_t)(2 * hp[i]); pb[half + i] = (uint16_t)(2 * hp[i] + 1); }
+        }
+    }
+    std::vector<unsigned> primes;
+    for (unsigned c = 2; primes.size() < 256; c++) {
+        bool is_prime = true;
+        for (unsigned p : primes) { if (p * p > c) break; if (c % p == 0) { is_prime = false; break; } }
+        if (is_prime) primes.push_back(c);
+    }
+    dims.resize(256);
+    table.clear();
+    for (unsigned d = 0; d < 256; d++) {
+        const unsigned b = primes[d];
+        unsigned digits = 1, P = b;
+        while ((unsigned long long)P * b <= 500ull) { P *= b; digits++; }      // table over the largest b^g <= 500
+        unsigned groups = 1;
+        unsigned long long full = P;
+        while (full * P < 4294967296ull) { full *= P; groups++; }               // groups with (b^g)^n < 2^32
+        dims[d].P = P; dims[d].n = groups; dims[d].off = (uint32_t)table.size();
+        dims[d].scale = float(0.9999998807907104 / (double)full);
+        for (unsigned i = 0; i < P; i++) {
+            unsigned rest = i;
+            uint16_t inv = 0;
+            for (unsigned k = 0; k < digits; ++k) { inv = (uint16_t)(inv * b + perm[b][rest % b]); rest /= b; }
+            table.push_back(inv);
+        }
+    }
+}
+
+inline HaltonEnumD make_halton_enum(unsigned width, unsigned height)  // Halton_enum ctor, include/halton_enum.h:69-104
+{
+    HaltonEnumD e;
+    unsigned w = 1, h = 1;
+    e.p2 = 0; while (w < width) { ++e.p2; w *= 2; }
+    e.p3 = 0; while (h < height) { ++e.p3; h *= 3; }
+    e.scale_x = float(w); e.scale_y = float(h);
+    e.inc = w * h;
+    // extended Euclid on (h, w), iterative: s0*h + t0*w == gcd == 1
+    long long a = (long long)h, b = (long long)w, s0 = 1, s1 = 0, t0 = 0, t1 = 1;
+    while (b) {
+        long long q = a / b, r = a % b;
+        a = b; b = r;
+        long long s2 = s0 - q * s1; s0 = s1; s1 = s2;
+        long long t2 = t0 - q * t1; t0 = t1; t1 = t2;
+    }
+    unsigned inv2 = (s0 < 0) ? (unsigned)(s0 + (long long)w) : (unsigned)(s0 % (long long)w);
+    unsigned inv3 = (t0 < 0) ? (unsigned)(t0 + (long long)h) : (unsigned)(t0 % (long long)h);
+    e.m_x = h * inv2;
+    e.m_y = w * inv3;
+    return e;
+}
+
+inline bool validate_scene(const gi_scene_desc* d, std::string& err)
+{
+    if (!d || d->n_tri < 0 || d->n_mat <= 0 || d->n_light < 0 || d->n_node <= 0) { err = "scene: bad counts"; return false; }
+    if (d->n_tri && (!d->tri_pos || !d->tri_nrm || !d->tri_mat)) { err = "scene: null triangle tables"; return false; }
+    if (!d->mats || !d->node_bbox || !d->node_child || !d->node_ent_off || (d->n_light && !d->lights)) { err = "scene: null tables"; return false; }
+    for (int i = 0; i < d->n_tri; i++)
+        if (d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_mat) { err = "scene: material index out of range"; return false; }
+    const int nref = d->node_ent_off[d->n_node];
+    if (d->node_ent_off[0] != 0 || nref < 0 || (nref && !d->node_ent_idx)) { err = "scene: bad leaf reference table"; return false; }
+    for (int n = 0; n < d->n_node; n++) {
+        if (d->node_ent_off[n + 1] < d->node_ent_off[n]) { err = "scene: leaf offsets not monotone"; return false; }
+        for (int k = 0; k < 8; k++) {
+            int ch = d->node_child[(size_t)n * 8 + k];
+            if (ch != -1 && (ch <= n || ch >= d->n_node)) { err = "scene: child index is not a later pre-order node"; return false; }
+        }
+    }
+    for (int r = 0; r < nref; r++)
+        if (d->node_ent_idx[r] < 0 || d->node_ent_idx[r] >= d->n_tri) { err = "scene: leaf reference out of range"; return false; }
+    return true;
+}
+
+// emit the direction-ordered pre-order copy `a` of the canonical tree (children visited as k ^ a: front to back for every
+// ray whose direction signs are `a`; child numbering x = bit0, z = bit1, y = bit2 as in include/octree.cpp:321-328)
+inline void emit_ordered(const gi_scene_desc* d, int a, int node, std::vector<TNode>& out)
+{
+    const size_t me = out.size();
+    TNode t;
+    for (int k = 0; k < 3; k++) { t.bmin[k] = d->node_bbox[(size_t)node * 6 + k]; t.bmax[k] = d->node_bbox[(size_t)node * 6 + 3 + k]; }
+    bool inner = false;
+    for (int k = 0; k < 8; k++) if (d->node_child[(size_t)node * 8 + k] >= 0) inner = true;
+    t.first_ref = d->node_ent_off[node];
+    t.n_ref = inner ? -1 : d->node_ent_off[node + 1] - d->node_ent_off[node];
+    t.leaf_id = node;
+    t.skip = 0;
+    out.push_back(t);
+    if (inner)
+        for (int k = 0; k < 8; k++) {
+            int ch = d->node_child[(size_t)node * 8 + (k ^ a)];
+            if (ch >= 0) emit_ordered(d, a, ch, out);
+        }
+    out[me].skip = (int32_t)out.size();
+}
+
+inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
+{
+    if (!validate_scene(d, err)) return false;
+    H.tnodes.clear();
+    H.tnodes.reserve((size_t)d->n_node * 8);
+    for (int a = 0; a < 8; a++) {
+        size_t before = H.tnodes.size();
+        emit_ordered(d, a, 0, H.tnodes);
+        if (H.tnodes.size() - before != (size_t)d->n_node) { err = "scene: octree is not one connected pre-order tree"; return false; }
+        for (size_t i = before; i < H.tnodes.size(); i++) H.tnodes[i].skip -= (int32_t)before;  // links relative to the copy
+    }
+    H.refs.assign(d->node_ent_idx, d->node_ent_idx + d->node_ent_off[d->n_node]);
+    H.tris.resize((size_t)d->n_tri);
+    H.shade.resize((size_t)d->n_tri);
+    for (int i = 0; i < d->n_tri; i++) {
+        const double* P = d->tri_pos + (size_t)i * 9;
+        const double* N = d->tri_nrm + (size_t)i * 9;
+        V3 p0 = ld3(P), p1 = ld3(P + 3), p2 = ld3(P + 6);
+        V3 e1 = p1 - p0, e2 = p2 - p0;
+        TriGeom& g = H.tris[i];
+        g.p0[0] = p0.x; g.p0[1] = p0.y; g.p0[2] = p0.z;
+        g.e1[0] = e1.x; g.e1[1] = e1.y; g.e1[2] = e1.z;
+        g.e2[0] = e2.x; g.e2[1] = e2.y; g.e2[2] = e2.z;
+        g.mat = d->tri_mat[i];
+        const double* m = d->mats + (size_t)g.mat * 9;
+        const bool smooth = len2(ld3(N)) > 0 && len2(ld3(N + 3)) > 0 && len2(ld3(N + 6)) > 0;   // include/entities.h:478
+        const bool always = (m[1] * 1.0 >= 1.0) || (m[2] != 1);                                  // include/raytracer.h:455
+        g.flags = (smooth ? 1u : 0u) | (always ? 2u : 0u);
+        TriShade& s = H.shade[i];
+        for (int k = 0; k < 3; k++) { s.n0[k] = N[k]; s.n1[k] = N[3 + k]; s.n2[k] = N[6 + k]; }
+        V3 fn = normalize(cross((p1 - p0), (p2 - p0)));                                          // include/entities.h:339
+        s.fnorm[0] = fn.x; s.fnorm[1] = fn.y; s.fnorm[2] = fn.z;
+    }
+    H.mats.resize((size_t)d->n_mat);
+    for (int i = 0; i < d->n_mat; i++) {
+        const double* m = d->mats + (size_t)i * 9;
+        H.mats[i].roughness = m[0]; H.mats[i].opacity = m[1]; H.mats[i].ior = m[2];
+        for (int k = 0; k < 3; k++) { H.mats[i].diffuse[k] = m[3 + k]; H.mats[i].emissive[k] = m[6 + k]; }
+    }
+    H.lights.resize((size_t)d->n_light);
+    for (int i = 0; i < d->n_light; i++) {
+        const double* l = d->lights + (size_t)i * 11;
+        for (int k = 0; k < 3; k++) { H.lights[i].pos[k] = l[k]; H.lights[i].col[k] = l[3 + k]; H.lights[i].dir[k] = l[7 + k]; }
+        H.lights[i].rad = l[6]; H.lights[i].angle = l[10];
+    }
+    H.n_node = d->n_node; H.n_tri = d->n_tri; H.n_light = d->n_light;
+    for (int k = 0; k < 3; k++) H.ambient[k] = d->ambient[k];
+    return true;
+}
+
+// photon octree: the input must be pre-order (first child = n+1, each next child where the previous sub-tree ends)
+inline bool layout_photons(const gi_photon_map_desc* d, HostPhotons& H, std::string& err)
+{
+    H.nodes.clear(); H.pos.clear(); H.dircol.clear(); H.n_node = 0; H.n_photon = 0;
+    if (d->n_node <= 0 || d->n_photon <= 0) return true;
+    if (!d->photons || !d->node_bbox || !d->node_child || !d->node_off) { err = "photons: null tables"; return false; }
+    const int nref = d->node_off[d->n_node];
+    if (d->node_off[0] != 0 || nref < 0 || (nref && !d->node_idx)) { err = "photons: bad leaf table"; return false; }
+    for (int r = 0; r < nref; r++)
+        if (d->node_idx[r] < 0 || d->node_idx[r] >= d->n_photon) { err = "photons: leaf reference out of range"; return false; }
+    std::vector<int32_t> skip((size_t)d->n_node, 0);
+    for (int n = d->n_node - 1; n >= 0; n--) {   // sub-tree end = max over children, children come later in pre-order
+        int32_t end = n + 1;
+        for (int k = 0; k < 8; k++) {
+            int ch = d->node_child[(size_t)n * 8 + k];
+            if (ch == -1) continue;
+            if (ch <= n || ch >= d->n_node) { err = "photons: child index is not a later pre-order node"; return false; }
+            end = std::max(end, skip[ch]);
+        }
+        skip[n] = end;
+    }
+    for (int n = 0; n < d->n_node; n++) {
+        int32_t expect = n + 1;
+        const bool leaf = d->node_child[(size_t)n * 8] == -1;
+        for (int k = 0; k < 8; k++) {
+            int ch = d->node_child[(size_t)n * 8 + k];
+            if (leaf) { if (ch != -1) { err = "photons: node with partial children"; return false; } continue; }
+            if (ch != expect) { err = "photons: nodes are not in pre-order"; return false; }
+            expect = skip[ch];
+        }
+    }
+    H.nodes.resize((size_t)d->n_node);
+    for (int n = 0; n < d->n_node; n++) {
+        PNode& t = H.nodes[n];
+        for (int k = 0; k < 3; k++) { t.bmin[k] = d->node_bbox[(size_t)n * 6 + k]; t.bmax[k] = d->node_bbox[(size_t)n * 6 + 3 + k]; }
+        t.skip = skip[n];
+        t.first = d->node_off[n];
+        t.count = d->node_off[n + 1] - d->node_off[n];
+        t.is_leaf = d->node_child[(size_t)n * 8] == -1 ? 1 : 0;
+        if (t.count < 0) { err = "photons: leaf offsets not monotone"; return false; }
+    }
+    H.pos.resize((size_t)nref * 3);
+    H.dircol.resize((size_t)nref * 6);
+    for (int r = 0; r < nref; r++) {
+        const double* p = d->photons + (size_t)d->node_idx[r] * 9;
+        for (int k = 0; k < 3; k++) H.pos[(size_t)r * 3 + k] = p[k];
+        for (int k = 0; k < 6; k++) H.dircol[(size_t)r * 6 + k] = p[3 + k];
+    }
+    H.n_node = d->n_node; H.n_photon = nref;
+    return true;
+}
+
+inline int local_rows(const gi_render_params* p)
+{
+    if (!p || p->stripe_h <= 0 || p->stripe_world <= 0 || p->height <= 0) return 0;
+    int rows = 0;
+    const int n_stripes = (p->height + p->stripe_h - 1) / p->stripe_h;
+    for (int k = p->stripe_rank; k < n_stripes; k += p->stripe_world) rows += std::min(p->stripe_h, p->height - k * p->stripe_h);
+    return rows;
+}
+
+// camera basis and frame constants, include/raytracer.h:74-78
+inline bool make_frame(const gi_render_params* p, Frame& F, std::string& err)
+{
+    if (!p || p->width <= 0 || p->height <= 0 || p->stripe_h <= 0 || p->stripe_world <= 0 || p->stripe_rank < 0 || p->stripe_rank >= p->stripe_world ||
+        p->min_samples < 0 || p->max_samples < 0) { err = "render: bad parameters"; return false; }
+    V3 pos = ld3(p->cam_pos), up = ld3(p->cam_up), fwd = ld3(p->cam_forward);
+    const int w = p->width, h = p->height;
+    F.sw = (p->sensor_diag * w) / (std::sqrt((double)w * w + h * h));
+    F.sh = F.sw * ((double)h / w);
+    F.screen_center = pos + p->focal_dist * fwd;
+    F.right = normalize(cross(fwd, up));
+    F.cam_pos = pos; F.cam_up = up;
+    F.w = w; F.h = h;
+    F.he = make_halton_enum((unsigned)w, (unsigned)h);
+    F.min_samples = p->min_samples; F.max_samples = p->max_samples; F.noise_thresh = p->noise_thresh;
+    F.seed = p->seed;
+    F.stripe_h = p->stripe_h; F.stripe_rank = p->stripe_rank; F.stripe_world = p->stripe_world;
+    F.local_rows = local_rows(p);
+    return true;
+}
+
+}  // namespace gi

@@ -1,0 +1,124 @@
+/* include/gi_hip.h -- C ABI of the MI355X (gfx950) render hot path of GI_Raytracer.
+ *
+ * This is the drop-in boundary (DESIGN.md "Boundary").  The reference has no FFI of its own: its
+ * de-facto interface is the public C++ surface of include/raytracer.h, include/octree.h, include/photonMap.h and
+ * include/entities.h.  The C++ headers under include/gi/ keep those spellings and are thin callers of the entry points
+ * below; a maintainer of the reference swaps the bodies of the cited functions for these calls.
+ *
+ * Conventions: every entry returns 0 on success and a negative GI_E_* code on failure; gi_last_error() gives the text;
+ * nothing throws, nothing prints.  All array arguments are caller-owned, read-only, plain host pointers and are copied
+ * to the device by the call that receives them.  One context is used from one thread at a time (the reference calls
+ * RayTracer::run from one worker thread, include/viewer.h:52-56).  There is NO CPU fallback: without a usable HIP
+ * device gi_create fails with GI_E_NO_DEVICE.
+ */
+#ifndef GI_HIP_H
+#define GI_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GI_OK 0
+#define GI_E_NO_DEVICE (-1)
+#define GI_E_INVALID (-2)
+#define GI_E_HIP (-3)
+#define GI_E_STATE (-4)
+#define GI_E_CANCELLED (-5)
+
+typedef struct gi_ctx gi_ctx;
+
+/* Flattened scene = what Octree holds after push_back()/rebuild() (include/octree.h:39-64, include/octree.cpp:25-119). */
+typedef struct gi_scene_desc {
+    int32_t n_tri;
+    const double* tri_pos;   /* [n_tri][3][3] vertex positions          (triangle::vertices[k].pos, include/entities.h:331) */
+    const double* tri_nrm;   /* [n_tri][3][3] vertex normals (all-zero row = flat shading, include/entities.h:478)          */
+    const double* tri_uv;    /* [n_tri][3][2] texture coordinates                                                           */
+    const int32_t* tri_mat;  /* [n_tri] index into mats                                                                     */
+    int32_t n_mat;
+    const double* mats;      /* [n_mat][9] roughness, opacity, IOR, diffuse rgb, emissive rgb (include/material.h:84-100)   */
+    int32_t n_light;
+    const double* lights;    /* [n_light][11] pos, col, rad, dir, angle (include/light.h:10-58; dir/angle from Octree::rebuild) */
+    double ambient[3];       /* RayTracer::ambient (include/raytracer.h:726)                                                */
+    /* linearised Octree: nodes in pre-order, children 0..7 as in Octree::Node::partition (include/octree.cpp:321-328)      */
+    int32_t n_node;
+    const double* node_bbox;     /* [n_node][6] min xyz, max xyz                                                            */
+    const int32_t* node_child;   /* [n_node][8] node index or -1 (null child)                                               */
+    const int32_t* node_ent_off; /* [n_node+1] range of node_ent_idx owned by the node (leaves only)                        */
+    const int32_t* node_ent_idx; /* [node_ent_off[n_node]] triangle indices in Node::_entities order                        */
+} gi_scene_desc;
+
+/* Photon set + linearised PhotonMap (include/photonMap.h:13-49, include/photon.h:5-15). */
+typedef struct gi_photon_map_desc {
+    int32_t n_photon;
+    const double* photons;       /* [n_photon][9] origin, dir, col                                                          */
+    int32_t n_node;              /* 0 = no map (gather returns 0, as an empty PhotonMap does)                                */
+    const double* node_bbox;     /* [n_node][6]                                                                             */
+    const int32_t* node_child;   /* [n_node][8] node index, or -1 in every slot for a leaf (PhotonMap::Node::is_leaf)       */
+    const int32_t* node_off;     /* [n_node+1] range of node_idx                                                            */
+    const int32_t* node_idx;     /* photon indices in Node::_entities order                                                 */
+} gi_photon_map_desc;
+
+/* Camera (include/camera.h:7-31) + frame + sampling budget (include/raytracer.h:721-726). */
+typedef struct gi_render_params {
+    double cam_pos[3], cam_up[3], cam_forward[3];
+    double sensor_diag, focal_dist;
+    int32_t width, height;
+    /* Row sharding for multi-GPU runs: the frame is cut into stripes of stripe_h rows; this context renders stripes
+     * k with k % stripe_world == stripe_rank.  Single GPU: stripe_h = height, rank 0, world 1.                            */
+    int32_t stripe_h, stripe_rank, stripe_world;
+    int32_t min_samples, max_samples;
+    double noise_thresh;
+    uint64_t seed;           /* counter-RNG seed (replaces the reference's time-seeded drand(), DESIGN.md "RNG contract")  */
+} gi_render_params;
+
+int gi_create(gi_ctx** out, int device_ordinal);
+void gi_destroy(gi_ctx*);
+const char* gi_last_error(const gi_ctx*);
+/* Launch kernels of this context on a caller-owned HIP stream (hipStream_t passed as void*; NULL = default stream). */
+int gi_set_stream(gi_ctx*, void* hip_stream);
+
+/* replaces: RayTracer::setScene + the tree walk of Octree::intersect/intersectSorted (include/raytracer.h:35-39,
+ * include/octree.cpp:150-211,256-313) -- uploads the tables every kernel reads                                           */
+int gi_upload_scene(gi_ctx*, const gi_scene_desc*);
+/* replaces: PhotonMap::push_back/rebuild as the source of the gather (include/photonMap.cpp:24-47)                         */
+int gi_upload_photons(gi_ctx*, const gi_photon_map_desc*);
+
+/* replaces: the pixel loop of RayTracer::run (include/raytracer.h:93-160) with radiance/trace/visible/secondaryRay/
+ * samplePhotons inside (include/raytracer.h:167-579).
+ * Number of rows this context renders for the given sharding: gi_local_rows().
+ * d_out_lin: DEVICE pointer to [local_rows][width][3] linear (pre-gamma, unclamped) radiance, float (out_is_f64 = 0) or
+ * double (1).  d_out_spp: optional DEVICE pointer to [local_rows][width] int32 samples taken (adaptive loop).
+ * cancel: optional host flag polled between launches (RayTracer::stop, include/raytracer.h:98,718).                        */
+int gi_local_rows(const gi_render_params*);
+int gi_render_device(gi_ctx*, const gi_render_params*, void* d_out_lin, int out_is_f64, int32_t* d_out_spp, volatile const int* cancel);
+/* Same, result copied to HOST memory (what a Qt-side caller wants). */
+int gi_render_host(gi_ctx*, const gi_render_params*, void* h_out_lin, int out_is_f64, int32_t* h_out_spp, volatile const int* cancel);
+/* Device time in ms of the render kernel(s) of the last gi_render_* call, measured with hipEvents on the launch stream. */
+int gi_last_render_ms(gi_ctx*, float* ms, int32_t* n_launches);
+/* Work counters of the last render (when enabled with gi_set_counters(ctx,1)): node visits in trace, node visits in
+ * visible, triangle tests, shaded hits, photon candidates, trace calls, shadow rays, gathers.                              */
+int gi_set_counters(gi_ctx*, int enable);
+int gi_get_counters(gi_ctx*, int64_t* out8);
+
+/* Function-level entry points (parity tests and the C++ API's public methods).  Host pointers.
+ * replaces RayTracer::trace (include/raytracer.h:382-478): rays [n][6] origin + unit dir -> hit, entity, res [n][8]        */
+int gi_trace(gi_ctx*, int32_t n, const double* rays, int32_t* hit, int32_t* ent, double* res);
+/* replaces RayTracer::visible (include/raytracer.h:280-319): q [n][6] = shadow-ray origin, target point                    */
+int gi_visible(gi_ctx*, int32_t n, const double* q, int32_t* vis);
+/* replaces RayTracer::samplePhotons(pos, dir, 32) (include/raytracer.h:532-579): q [n][6] = pos, dir                       */
+int gi_gather(gi_ctx*, int32_t n, const double* q, double* res3, int32_t* n_cand);
+/* replaces RayTracer::radiance(ray, 0, ...) (include/raytracer.h:167-276): rays [n][6], stream [n] = Halton sample index  */
+int gi_radiance(gi_ctx*, int32_t n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3);
+/* replaces RayTracer::tracePhotons (include/raytracer.h:582-715): emits `count` photon indices per light on the device;
+ * photons_out [cap][9]; returns the number stored (<= count * n_light) or a negative error; tries_out = emission tries.    */
+int gi_emit_photons(gi_ctx*, int32_t count, int32_t max_depth, uint64_t seed, double* photons_out, int32_t cap, int64_t* tries_out);
+
+/* Halton_sampler::sample / Halton_enum::get_index on the device tables (include/halton_sampler.h:626-888,
+ * include/halton_enum.h:106-114) -- known-answer access for tests                                                          */
+int gi_halton_sample(gi_ctx*, int32_t n, const uint32_t* dim, const uint32_t* index, float* out);
+int gi_halton_index(gi_ctx*, int32_t width, int32_t height, int32_t n, const uint32_t* sxy /*[n][3]*/, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

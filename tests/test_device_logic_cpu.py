@@ -1,0 +1,61 @@
+"""Kernel logic on the CPU: the per-lane device functions of gi_raytracer_amd/csrc/gi_device.h compiled for the host
+(tests/host_emul) and checked against the reference's golden tables and against the oracle.  This is NOT the product
+path (the product has no CPU path); it exists so that logic errors are caught where there is no GPU."""
+import numpy as np
+import pytest
+
+import emul_lib as el
+import parity_checks as pc
+
+
+@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics"])
+def setup(request, golden):
+    scene = pc.load_scene(request.param)
+    return request.param, scene, el.EmulRayTracer().setScene(scene), golden("scene_" + request.param)
+
+
+def test_halton_device_tables(golden):
+    pc.check_halton(el.EmulRayTracer(), golden)
+
+
+def test_counter_rng_matches_oracle():
+    import oracle_lib as ol
+    L, E = ol.lib(), el.lib()
+    rs = np.random.RandomState(1)
+    for _ in range(200):
+        a = [int(v) for v in rs.randint(0, 2**31, 6)]
+        assert L.gio_counter_rand(a[0] * 7919, a[1], a[2] % 70, a[3] % 4096, a[4], a[5]) == E.emul_rng(a[0] * 7919, a[1], a[2] % 70, a[3] % 4096, a[4], a[5])
+
+
+def test_trace_matches_reference_table(setup):
+    pc.check_trace_table(setup[2], setup[3])
+
+
+def test_visible_matches_reference_table(setup):
+    pc.check_visible_table(setup[2], setup[3])
+
+
+def test_gather_matches_reference_table(setup):
+    name, scene, rt, fx = setup
+    if "photons" not in fx:
+        pytest.skip("no photons in this scene")
+    pc.check_gather_table(rt, scene, fx)
+
+
+def test_emission_identical_to_oracle(setup):
+    name, scene, rt, fx = setup
+    if scene.desc().n_light == 0:
+        pytest.skip("no light")
+    pc.check_emission(rt, scene, 1500)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_render_matches_oracle(setup, adaptive):
+    name, scene, rt, fx = setup
+    rmse, _, _ = pc.check_render(rt, scene, 40, 24, 4, 2000, adaptive)
+    assert rmse < 1e-12
+
+
+def test_stripe_sharding_is_exact(setup):
+    name, scene, rt, fx = setup
+    pc.check_stripes(rt, scene, 24, 21, 2, world=3, stripe_h=4)

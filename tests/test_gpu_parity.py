@@ -1,0 +1,137 @@
+"""Parity of the HIP path (through the C ABI of libgi_raytracer_hip.so) on a real MI355X.
+
+Small cases: compared with the reference's golden tables and with the CPU oracle on the same seeded inputs.
+Full BASELINE sizes: size-independent properties (stripe interleave identity, determinism, sample-count invariants,
+energy bounds) -- the oracle would need minutes there.
+Tolerances: integer / index results exact; hit points and normals bit-exact (same IEEE operations, no contraction);
+radiance RMSE < 1e-4 (north_star), measured ~1e-16.
+"""
+import numpy as np
+import pytest
+
+import gi_raytracer_amd as gi
+import parity_checks as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt0():
+    return gi.RayTracer(0)
+
+
+@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics"])
+def setup(request, golden):
+    scene = pc.load_scene(request.param)
+    return request.param, scene, gi.RayTracer(0).setScene(scene), golden("scene_" + request.param)
+
+
+def test_halton_device_tables(rt0, golden):
+    pc.check_halton(rt0, golden)
+
+
+def test_trace_matches_reference_table(setup):
+    pc.check_trace_table(setup[2], setup[3])
+
+
+def test_visible_matches_reference_table(setup):
+    pc.check_visible_table(setup[2], setup[3])
+
+
+def test_gather_matches_reference_table(setup):
+    name, scene, rt, fx = setup
+    if "photons" not in fx:
+        pytest.skip("no photons in this scene")
+    pc.check_gather_table(rt, scene, fx)
+
+
+def test_emission_identical_to_oracle(setup):
+    name, scene, rt, fx = setup
+    if scene.desc().n_light == 0:
+        pytest.skip("no light")
+    pc.check_emission(rt, scene, 3000)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_render_matches_oracle(setup, adaptive):
+    name, scene, rt, fx = setup
+    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, adaptive)
+    assert rmse < 1e-9, rmse      # far inside the 1e-4 contract: any larger value means a diverged path
+
+
+def test_radiance_entry_matches_oracle(setup):
+    name, scene, rt, fx = setup
+    o = pc.oracle_for(scene)
+    ph = np.zeros((0, 9))
+    if scene.desc().n_light:
+        ph, _ = rt.tracePhotons(2000)
+    o.set_photons(ph).build_photon_map()
+    rays = fx["rays"][:4000]
+    stream = np.arange(len(rays), dtype=np.uint32) * 7919
+    got, ref = rt.radiance(rays, stream), o.radiance(rays, stream, rt.seed)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 1e-9
+
+
+def test_stripe_sharding_is_exact(setup):
+    name, scene, rt, fx = setup
+    pc.check_stripes(rt, scene, 64, 50, 2, world=4, stripe_h=8)
+
+
+def test_empty_and_edge_inputs(setup):
+    name, scene, rt, fx = setup
+    hit, ent, res = rt.trace(np.zeros((0, 6)))
+    assert len(hit) == 0
+    assert len(rt.visible(np.zeros((0, 6)))) == 0
+    # a ray that starts outside the root box and points away misses; axis-parallel rays (infinite inverse components) work
+    away = np.array([[100.0, 100.0, 100.0, 0.0, 1.0, 0.0]])
+    assert rt.trace(away)[0][0] == 0
+    # 0 samples per pixel: the running mean keeps its initial 0.5 (include/raytracer.h:102)
+    img = rt.run(8, 8, min_samples=0, max_samples=0)
+    assert (img == 0.5).all()
+    # 1x1 frame
+    assert rt.run(1, 1, min_samples=1, max_samples=1).shape == (1, 1, 3)
+
+
+def test_no_photon_map_gather_is_zero():
+    scene = pc.load_scene("caustics")
+    rt = gi.RayTracer(0).setScene(scene)
+    res, nc = rt.samplePhotons(np.array([[0.0, 0.0, 0.0, 0.0, 1.0, 0.0]]))
+    assert (res == 0).all() and nc[0] == 0
+
+
+def test_errors_are_reported_not_swallowed():
+    rt = gi.RayTracer(0)
+    with pytest.raises(gi.GiError):
+        rt.trace(np.zeros((1, 6)))            # no scene uploaded
+    with pytest.raises(gi.GiError):
+        gi.RayTracer(99)                      # no such device
+
+
+@pytest.mark.parametrize("name,w,h,spp,photons", [("test_scene", 256, 256, 1, 0), ("cornell", 512, 512, 4, 0), ("caustics", 1920, 1080, 2, 20000)])
+def test_full_size_properties(name, w, h, spp, photons):
+    """BASELINE frame sizes (configs 1-3) at reduced spp: properties that do not need the oracle."""
+    scene = pc.load_scene(name)
+    rt = gi.RayTracer(0).setScene(scene)
+    if photons and scene.desc().n_light:
+        rt.tracePhotons(photons)
+    a, na = rt.run(w, h, min_samples=spp, max_samples=spp, want_spp=True)
+    assert (na == spp).all() and np.isfinite(a).all() and (a >= 0).all()
+    b = rt.run(w, h, min_samples=spp, max_samples=spp)
+    assert np.array_equal(a, b)                                   # deterministic: counter RNG + Halton, no races
+    # stripes of 16 rows over 8 ranks interleave back to the same frame (the multi-GPU decomposition)
+    frame = np.zeros_like(a)
+    for rank in range(8):
+        frame[pc.stripe_rows(h, 16, rank, 8)] = rt.run(w, h, min_samples=spp, max_samples=spp, stripe_h=16, rank=rank, world=8)
+    assert np.array_equal(frame, a)
+    # float32 output is the rounding of the float64 output
+    c = rt.run(w, h, min_samples=spp, max_samples=spp, f64=False)
+    assert np.array_equal(c, a.astype(np.float32))
+    if name == "test_scene":
+        assert (a == 0).all()          # no light, ambient 0, emissive 0: the reference image is black
+    # a sub-window of the frame agrees with the oracle (seconds on the CPU)
+    if name != "test_scene":
+        o = pc.oracle_for(scene)
+        ph = scene.photon_tables()["photons"]
+        o.set_photons(ph).build_photon_map()
+        ref = o.render(w, h, spp, y0=h // 2, y1=h // 2 + 4)["lin"][h // 2:h // 2 + 4]
+        assert np.sqrt(((a[h // 2:h // 2 + 4] - ref) ** 2).mean()) < 1e-9
