@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the render hot path on MI355X (BASELINE.json metric).
+
+One step = one frame of the workload: caustics scene (scenes/caustics), 1920x1080, 256 spp, 200 000 photon indices emitted
+and built into the photon map before the timed region (BASELINE.json configs[2], the configuration the metric is quoted
+on).  1 sample = one radiance() evaluation: primary ray + the whole path (bounces, shadow rays, photon gathers).
+
+N GPUs: one process per GPU (torch.distributed / RCCL).  The frame is cut into 16-row stripes dealt round-robin to the
+ranks (strong scaling: the frame is fixed); every step ends with one RCCL gather of the float-RGB stripes to rank 0, which
+is inside the timed region.  Timing: barrier + torch.cuda.synchronize() on both sides of exactly K steps, MAX over ranks.
+
+Extra objects on the JSON line: "roofline" (algorithmic HBM bytes of the render kernel / its HIP-event duration, against
+8 TB/s) and, at N=1, "cpu_baseline" (the CPU oracle, OpenMP on the box's host cores, on a bounded sample of the same
+workload: full-width rows spread over the frame at the full 256 spp).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+STRIPE_H = 16
+
+
+def algorithmic_bytes_per_sample(counters, n_samples, spp):
+    """B = 32 V + 36 T + 96 H + 36 P + 12/spp with V node visits (trace + visible), T ray-triangle tests,
+    H shaded hits, P photon candidates per sample, counted by the CPU oracle on the same workload."""
+    v = (counters[0] + counters[1]) / n_samples
+    t = counters[2] / n_samples
+    hh = counters[3] / n_samples
+    p = counters[4] / n_samples
+    return 32 * v + 36 * t + 96 * hh + 36 * p + 12.0 / spp, {"V": v, "T": t, "H": hh, "P": p}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="caustics")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--photons", type=int, default=200000)
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (-1: sized for ~20 s, 0: skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gi_raytracer_amd as gi
+    import parity_checks as pc
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the render hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- setup (untimed): scene tables, octree, photon emission on the device, photon octree
+    scene = pc.load_scene(args.scene)
+    rt = gi.RayTracer(local_rank).setScene(scene)
+    rt.set_stream(torch.cuda.current_stream().cuda_stream)
+    t0 = time.time()
+    n_photons = 0
+    if args.photons > 0 and scene.desc().n_light > 0:
+        ph, tries = rt.tracePhotons(args.photons)
+        n_photons = len(ph)
+    setup_s = time.time() - t0
+
+    w, h, spp = args.width, args.height, args.spp
+    stripe_h = STRIPE_H if world > 1 else h
+    p = rt.params(w, h, stripe_h=stripe_h, rank=rank, world=world, min_samples=spp, max_samples=spp)
+    rows = rt.local_rows(p)
+    max_rows = max(len(pc.stripe_rows(h, stripe_h, r, world)) for r in range(world))
+    local = torch.zeros((max_rows, w, 3), dtype=torch.float32, device=dev)
+    gathered = [torch.zeros_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    frame = torch.zeros((h, w, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    row_index = [torch.as_tensor(pc.stripe_rows(h, stripe_h, r, world), device=dev) for r in range(world)] if rank == 0 else None
+
+    kernel_ms = []
+
+    def step(record):
+        rt.run_device(p, local.data_ptr(), f64=False)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    frame[row_index[r]] = gathered[r][: len(row_index[r])]
+        if record:
+            kernel_ms.append(rt.last_render_ms()[0])   # HIP events on the launch stream (synchronises on the second event)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        km = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_ms_avg = float(km.item())
+    else:
+        kernel_ms_avg = float(np.mean(kernel_ms))
+
+    if rank == 0:
+        samples_per_step = w * h * spp
+        value = samples_per_step * args.steps / elapsed / 1e6
+        img = (frame if world > 1 else local[:h]).cpu().numpy()
+        out = {
+            "metric": "Msamples/sec (primary+path rays) at 1080p", "value": value, "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"scenes/{args.scene} {w}x{h} {spp} spp, {args.photons} photon indices ({n_photons} photons stored) + gather",
+                       "frame": [w, h], "spp": spp, "photons_stored": n_photons, "sharding": f"{STRIPE_H}-row stripes round-robin over {world} GPU(s), RCCL gather to rank 0" if world > 1 else "single GPU",
+                       "setup_s_untimed": round(setup_s, 3), "mean_radiance": float(img.mean())},
+        }
+        # ---- CPU baseline + algorithmic bytes (oracle = the checker, timed on the host cores; N=1 only)
+        cpu = None
+        bytes_per_sample, mix = None, None
+        if world == 1 and not args.no_cpu and args.cpu_rows != 0:
+            import oracle_lib as ol
+            o = pc.oracle_for(scene)
+            o.set_photons(scene.photon_tables()["photons"]).build_photon_map()
+            cores = os.cpu_count() or 1
+            n_rows = args.cpu_rows
+            if n_rows < 0:
+                # calibrate on one row per core, then size the sample for ~20 s of CPU work
+                probe = np.unique(np.linspace(0, h - 1, cores).round().astype(np.int32))
+                tc = time.perf_counter()
+                o.render_rows(w, h, probe, spp, rt.seed)
+                t_probe = time.perf_counter() - tc
+                n_rows = int(min(h, max(cores, len(probe) * 20.0 / max(t_probe, 1e-6))))
+            rows_sel = np.unique(np.linspace(0, h - 1, n_rows).round().astype(np.int32))
+            tc = time.perf_counter()
+            lin, cnt = o.render_rows(w, h, rows_sel, spp, rt.seed)
+            cpu_s = time.perf_counter() - tc
+            n_s = len(rows_sel) * w * spp
+            cpu = {"value": n_s / cpu_s / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+                   "sample": f"{len(rows_sel)} full-width rows spread evenly over the {w}x{h} frame at {spp} spp = {n_s} samples in {cpu_s:.1f} s (OpenMP oracle, rows dealt dynamically to {cores} threads)"}
+            bytes_per_sample, mix = algorithmic_bytes_per_sample(cnt, n_s, spp)
+            # parity of the timed frame against the oracle on exactly those rows
+            rmse = float(np.sqrt(((img[rows_sel].astype(np.float64) - lin[rows_sel]) ** 2).mean()))
+            out["config"]["rmse_vs_oracle_on_cpu_rows"] = rmse
+        if bytes_per_sample is None:
+            # per-sample mix measured by the oracle on this workload (profiles/r01_notes.md); used when the CPU leg is skipped
+            bytes_per_sample, mix = 32 * 93.0 + 36 * 62.6 + 96 * 0.95 + 36 * 70.0 + 12.0 / spp, None
+        local_samples = rows * w * spp
+        achieved = bytes_per_sample * local_samples / (kernel_ms_avg * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "k_render", "kernel_ms": kernel_ms_avg, "algorithmic_bytes_per_sample": bytes_per_sample,
+                           "per_sample_mix": mix}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

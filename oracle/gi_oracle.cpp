@@ -1257,9 +1257,9 @@ int gio_gather(gio_ctx* c, int n, const double* q, double* res3, int32_t* n_cand
     return 0;
 }
 
-int gio_render(gio_ctx* c, int w, int h, int y0, int y1, int min_samples, int max_samples, double noise_thresh,
-               int rng_mode, uint64_t seed, int chain_predraws, int n_threads,
-               double* out_lin, uint8_t* out_u8, int32_t* out_spp, int64_t* counters)
+static int render_rows(gio_ctx* c, int w, int h, int n_rows, const int32_t* rows, int min_samples, int max_samples, double noise_thresh,
+                       int rng_mode, uint64_t seed, int chain_predraws, int n_threads,
+                       double* out_lin, uint8_t* out_u8, int32_t* out_spp, int64_t* counters)
 {
     if (!c->octree_valid) return -1;
     HaltonEnum he;
@@ -1279,8 +1279,10 @@ int gio_render(gio_ctx* c, int w, int h, int y0, int y1, int min_samples, int ma
         Rng rng_local;
         rng_local.mode = GIO_RNG_COUNTER;
         rng_local.seed = seed;
-#pragma omp for schedule(dynamic, 10)
-        for (int y = y0; y < y1; y++) {
+        // the reference deals rows in chunks of 10 (raytracer.h:93); chunks of 1 keep every core busy on a short row list
+#pragma omp for schedule(dynamic, 1)
+        for (int ri = 0; ri < n_rows; ri++) {
+            const int y = rows[ri];
             for (int x = 0; x < w; x++) {
                 Rng& rng = (rng_mode == GIO_RNG_CHAIN) ? chain : rng_local;
                 V3 lin;
@@ -1311,6 +1313,22 @@ int gio_render(gio_ctx* c, int w, int h, int y0, int y1, int min_samples, int ma
         counters[4] = total.pcand; counters[5] = total.traces; counters[6] = total.shadows; counters[7] = total.gathers;
     }
     return 0;
+}
+
+int gio_render(gio_ctx* c, int w, int h, int y0, int y1, int min_samples, int max_samples, double noise_thresh,
+               int rng_mode, uint64_t seed, int chain_predraws, int n_threads,
+               double* out_lin, uint8_t* out_u8, int32_t* out_spp, int64_t* counters)
+{
+    std::vector<int32_t> rows;
+    for (int y = y0; y < y1; y++) rows.push_back(y);
+    return render_rows(c, w, h, (int)rows.size(), rows.data(), min_samples, max_samples, noise_thresh, rng_mode, seed, chain_predraws, n_threads, out_lin, out_u8, out_spp, counters);
+}
+
+int gio_render_rows(gio_ctx* c, int w, int h, int n_rows, const int32_t* rows, int min_samples, int max_samples, double noise_thresh,
+                    uint64_t seed, int n_threads, double* out_lin, int64_t* counters)
+{
+    for (int i = 0; i < n_rows; i++) if (rows[i] < 0 || rows[i] >= h) return -2;
+    return render_rows(c, w, h, n_rows, rows, min_samples, max_samples, noise_thresh, GIO_RNG_COUNTER, seed, 0, n_threads, out_lin, nullptr, nullptr, counters);
 }
 
 int gio_radiance(gio_ctx* c, int n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3)

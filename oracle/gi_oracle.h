@@ -78,6 +78,10 @@ int gio_render(gio_ctx*, int w, int h, int y0, int y1, int min_samples, int max_
                int rng_mode, uint64_t seed, int chain_predraws, int n_threads,
                double* out_lin, uint8_t* out_u8, int32_t* out_spp, int64_t* counters);
 
+/* Same pixel loop over an explicit list of frame rows (counter RNG): the bounded CPU-baseline sample of bench.py. */
+int gio_render_rows(gio_ctx*, int w, int h, int n_rows, const int32_t* rows, int min_samples, int max_samples, double noise_thresh,
+                    uint64_t seed, int n_threads, double* out_lin, int64_t* counters);
+
 /* radiance() of explicit primary rays under the counter RNG: rays [n][6], stream[n] = halton sample index */
 int gio_radiance(gio_ctx*, int n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3);
 

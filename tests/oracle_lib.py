@@ -80,6 +80,8 @@ def lib():
         L.gio_gather.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_ip]
         L.gio_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                  C.c_uint64, C.c_int, C.c_int, c_dp, C.POINTER(C.c_uint8), c_ip, C.POINTER(C.c_int64)]
+        L.gio_render_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_ip, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int, c_dp,
+                                      C.POINTER(C.c_int64)]
         L.gio_radiance.argtypes = [C.c_void_p, C.c_int, c_dp, c_up, C.c_uint64, c_dp]
         _LIB = L
     return _LIB
@@ -242,6 +244,15 @@ class Oracle:
         if want_counters:
             out["counters"] = cnt
         return out
+
+    def render_rows(self, w, h, rows, spp, seed=DEFAULT_SEED, n_threads=0):
+        """Full-width rows `rows` of a w x h frame at fixed spp; returns (lin [h][w][3] with only those rows filled, counters[8])."""
+        rows = np.ascontiguousarray(rows, np.int32)
+        lin = np.zeros((h, w, 3)); cnt = np.zeros(8, np.int64)
+        r = self.L.gio_render_rows(self.h, w, h, len(rows), _ptr(rows, c_ip), spp, spp, 0.0, C.c_uint64(seed), n_threads, _ptr(lin, c_dp),
+                                   _ptr(cnt, C.POINTER(C.c_int64)))
+        assert r == 0
+        return lin, cnt
 
     def radiance(self, rays, stream, seed=DEFAULT_SEED):
         rays = np.ascontiguousarray(rays, np.float64)
