@@ -149,18 +149,18 @@ def main():
             import oracle_lib as ol
             o = pc.oracle_for(scene)
             o.set_photons(scene.photon_tables()["photons"]).build_photon_map()
-            cores = os.cpu_count() or 1
+            cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("GI_CPU_THREADS", "16"))))   # the box's CPU share for one GPU
             n_rows = args.cpu_rows
             if n_rows < 0:
                 # calibrate on one row per core, then size the sample for ~20 s of CPU work
                 probe = np.unique(np.linspace(0, h - 1, cores).round().astype(np.int32))
                 tc = time.perf_counter()
-                o.render_rows(w, h, probe, spp, rt.seed)
+                o.render_rows(w, h, probe, spp, rt.seed, cores)
                 t_probe = time.perf_counter() - tc
                 n_rows = int(min(h, max(cores, len(probe) * 20.0 / max(t_probe, 1e-6))))
             rows_sel = np.unique(np.linspace(0, h - 1, n_rows).round().astype(np.int32))
             tc = time.perf_counter()
-            lin, cnt = o.render_rows(w, h, rows_sel, spp, rt.seed)
+            lin, cnt = o.render_rows(w, h, rows_sel, spp, rt.seed, cores)
             cpu_s = time.perf_counter() - tc
             n_s = len(rows_sel) * w * spp
             cpu = {"value": n_s / cpu_s / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
