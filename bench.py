@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--photons", type=int, default=200000)
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (-1: sized for ~20 s, 0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mode", default="wavefront", choices=["wavefront", "megakernel"])
     args = ap.parse_args()
 
     import torch
@@ -78,6 +79,7 @@ def main():
     scene = pc.load_scene(args.scene)
     rt = gi.RayTracer(local_rank).setScene(scene)
     rt.set_stream(torch.cuda.current_stream().cuda_stream)
+    rt.set_render_mode(args.mode)
     t0 = time.time()
     n_photons = 0
     if args.photons > 0 and scene.desc().n_light > 0:

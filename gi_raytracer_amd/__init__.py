@@ -54,7 +54,7 @@ _LIB = None
 # every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
-    "gi_render_device", "gi_render_host", "gi_last_render_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
+    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_pool_slots", "gi_last_render_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_light", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
@@ -81,6 +81,8 @@ def lib():
     L.gi_local_rows.argtypes = [C.POINTER(RenderParams)]
     L.gi_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int, vp, vp]
     L.gi_render_host.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int, vp, vp]
+    L.gi_set_render_mode.argtypes = [vp, C.c_int]
+    L.gi_set_pool_slots.argtypes = [vp, C.c_int64]
     L.gi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), _ip]
     L.gi_set_counters.argtypes = [vp, C.c_int]
     L.gi_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -320,6 +322,13 @@ class RayTracer:
     def run_device(self, p, out_ptr, f64=False, spp_ptr=None):
         """Render into device memory (bench / multi-GPU path); out_ptr is a raw device pointer."""
         self._check(self.L.gi_render_device(self.h, C.byref(p), C.c_void_p(out_ptr), 1 if f64 else 0, C.c_void_p(spp_ptr) if spp_ptr else None, None), "render_device")
+
+    def set_render_mode(self, mode):
+        """'wavefront' (default) or 'megakernel': two schedules of the same per-path arithmetic."""
+        self._check(self.L.gi_set_render_mode(self.h, {"wavefront": 0, "megakernel": 1}[mode]), "set_render_mode")
+
+    def set_pool_slots(self, slots):
+        self._check(self.L.gi_set_pool_slots(self.h, int(slots)), "set_pool_slots")
 
     def last_render_ms(self):
         ms, n = C.c_float(), C.c_int32()

@@ -374,31 +374,33 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
 }
 
 // ------------------------------------------------------------------------------------------------ photon gather
-// Lane-private max-heap of GI_GATHER_K doubles; element i of this lane lives at hp[i * stride] (LDS, bank-conflict free
-// for any per-lane i because the lane index is the fastest-varying address component).
-struct Heap { double* hp; int stride; int n; };
-GI_HD void heap_push(Heap& h, double x)
+// Lane-private max-heap of GI_GATHER_K *float* keys; element i of this lane lives at hp[i * stride] (LDS, bank-conflict free
+// for any per-lane i because the lane index is the fastest-varying address component).  Keys are (float)d2: rounding is
+// monotone, so key(a) < key(b) implies d2(a) < d2(b); only candidates whose key EQUALS the 32nd key are ambiguous and those
+// are resolved with exact doubles below.  8 KB of LDS per wave instead of 16.
+struct Heap { float* hp; int stride; int n; };
+GI_HD void heap_push(Heap& h, float x)
 {
     int i = h.n++;
     while (i > 0) {
         int p = (i - 1) >> 1;
-        double pv = h.hp[p * h.stride];
+        float pv = h.hp[p * h.stride];
         if (pv >= x) break;
         h.hp[i * h.stride] = pv;
         i = p;
     }
     h.hp[i * h.stride] = x;
 }
-GI_HD void heap_replace_root(Heap& h, double x)
+GI_HD void heap_replace_root(Heap& h, float x)
 {
     int i = 0;
     for (;;) {
         int l = 2 * i + 1;
         if (l >= h.n) break;
         int cidx = l;
-        double cv = h.hp[l * h.stride];
+        float cv = h.hp[l * h.stride];
         if (l + 1 < h.n) {
-            double rv = h.hp[(l + 1) * h.stride];
+            float rv = h.hp[(l + 1) * h.stride];
             if (rv > cv) { cidx = l + 1; cv = rv; }
         }
         if (cv <= x) break;
@@ -412,9 +414,11 @@ GI_HD bool boxes_touch(const double* amin, const double* amax, const double* qmi
     return (amin[0] <= qmax[0] && amax[0] >= qmin[0]) && (amin[1] <= qmax[1] && amax[1] >= qmin[1]) && (amin[2] <= qmax[2] && amax[2] >= qmin[2]);
 }
 // RayTracer::samplePhotons(pos, dir, 32): candidates = photons of every leaf touching the (+-EPSILON) box of the leaf that
-// contains pos; the 32 nearest of them; sum col*dot(photon.dir, dir) / (pi * r32^2).  Two passes over the candidates:
-// pass 1 finds r32^2 with the heap, pass 2 accumulates everything inside it.
-GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, double* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
+// contains pos; the 32 nearest of them; sum col*dot(photon.dir, dir) / (pi * r32^2).
+//   pass 1: 32nd smallest float key tau (heap);   pass 2: exact sums of everything with key < tau, and of the key == tau group;
+//   if the tie group is larger than what is still needed (float ties straddling rank 32: rare) pass 3 picks the needed ones by
+//   exact distance.
+GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
 {
     V3 res = v3(0, 0, 0);
     if (n_cand_out) *n_cand_out = 0;
@@ -445,7 +449,7 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, double* heap_mem, int heap_strid
     Heap h;
     h.hp = heap_mem; h.stride = heap_stride; h.n = 0;
     int ncand = 0;
-    double root = 0;
+    float tau = 0;
     node = 0;
     while (node < S.n_pnode) {
         const PNode& nd = S.pnodes[node];
@@ -453,9 +457,9 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, double* heap_mem, int heap_strid
         if (!nd.is_leaf) { node = node + 1; continue; }
         for (int32_t k = 0; k < nd.count; k++) {
             const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
-            double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
-            if (h.n < GI_GATHER_K) { heap_push(h, d2); root = h.hp[0]; }
-            else if (d2 < root) { heap_replace_root(h, d2); root = h.hp[0]; }
+            float key = (float)len2(v3(pp[0], pp[1], pp[2]) - pos);
+            if (h.n < GI_GATHER_K) { heap_push(h, key); tau = h.hp[0]; }
+            else if (key < tau) { heap_replace_root(h, key); tau = h.hp[0]; }
         }
         ncand += nd.count;
         node = nd.skip;
@@ -465,8 +469,9 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, double* heap_mem, int heap_strid
     if (ncand == 0) return res;
     const int K = ncand < GI_GATHER_K ? ncand : GI_GATHER_K;
     // pass 2
-    V3 s_lt = v3(0, 0, 0), s_tie = v3(0, 0, 0);
-    int c_lt = 0, c_tie = 0;
+    V3 s_lt = v3(0, 0, 0), s_eq = v3(0, 0, 0);
+    int c_lt = 0, c_eq = 0;
+    double r_eq = 0;
     node = 0;
     while (node < S.n_pnode) {
         const PNode& nd = S.pnodes[node];
@@ -475,19 +480,49 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, double* heap_mem, int heap_strid
         for (int32_t k = 0; k < nd.count; k++) {
             const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
             double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
-            if (d2 <= root) {
+            float key = (float)d2;
+            if (key <= tau) {
                 const double* dc = S.ph_dircol + (size_t)(nd.first + k) * 6;
                 V3 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
-                if (d2 < root) { s_lt = s_lt + contrib; c_lt++; }
-                else { s_tie = s_tie + contrib; c_tie++; }
+                if (key < tau) { s_lt = s_lt + contrib; c_lt++; }
+                else { s_eq = s_eq + contrib; c_eq++; r_eq = d2 > r_eq ? d2 : r_eq; }
             }
         }
         node = nd.skip;
     }
-    const int need = K - c_lt;  // >= 1: the heap root itself is a candidate at distance == root
-    if (c_tie <= need) res = s_lt + s_tie;
-    else res = s_lt + s_tie * ((double)need / (double)c_tie);  // equal-distance photons straddling rank 32: unspecified in the reference
-    res = res / (GI_PI * root);
+    const int need = K - c_lt;  // >= 1: the heap root itself is a candidate with key == tau
+    double r2;
+    if (c_eq <= need) { res = s_lt + s_eq; r2 = r_eq; }
+    else {
+        // pass 3 (rare): the `need` nearest of the tie group by exact distance, one extraction per scan
+        res = s_lt;
+        double last = -1.0;
+        for (int j = 0; j < need; j++) {
+            double best = INFINITY;
+            V3 bc = v3(0, 0, 0);
+            node = 0;
+            while (node < S.n_pnode) {
+                const PNode& nd = S.pnodes[node];
+                if (node != 0 && !boxes_touch(nd.bmin, nd.bmax, qmin, qmax)) { node = nd.skip; continue; }
+                if (!nd.is_leaf) { node = node + 1; continue; }
+                for (int32_t k = 0; k < nd.count; k++) {
+                    const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
+                    double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
+                    if ((float)d2 == tau && d2 > last && d2 < best) {
+                        const double* dc = S.ph_dircol + (size_t)(nd.first + k) * 6;
+                        best = d2;
+                        bc = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
+                    }
+                }
+                node = nd.skip;
+            }
+            if (best == INFINITY) break;   // exact duplicates exhausted the group
+            res = res + bc;
+            last = best;
+        }
+        r2 = last;
+    }
+    res = res / (GI_PI * r2);
     return res;
 }
 
@@ -544,56 +579,128 @@ GI_HD V3 shading_normal(const Scene& S, const HitRec& h)  // include/entities.h:
     return ld3(sh.fnorm);
 }
 
-// One path: RayTracer::radiance(ray, 0, ..., sample, (1,1,1)) as a loop.  L = A_0 + f_0 (A_1 + f_1 (A_2 + ...)) is
-// accumulated as sum_k (prod_{j<k} f_j) A_k with A = color*i + emissive + color*caustic on continue, color*i on a failed
-// roulette, ambient on a miss and 0 past MAX_DEPTH.
-GI_HD V3 radiance_path(const Scene& S, Ray ray, uint32_t sample, uint64_t seed, double* heap_mem, int heap_stride, Counters* c)
+// ---- one path as explicit stages (the recursion of RayTracer::radiance turned into a loop carrying the throughput).
+// L = A_0 + f_0 (A_1 + f_1 (A_2 + ...)) is accumulated as sum_k (prod_{j<k} f_j) A_k with A = color*i + emissive (+ color*caustic,
+// added by the gather stage) on continue, color*i on a failed roulette, ambient on a miss and 0 past MAX_DEPTH.
+// The megakernel runs the stages back to back per lane; the wavefront pipeline runs each stage as its own kernel over a
+// compacted queue of PathRec indices (gi_kernels.hip).
+struct alignas(16) PathRec {    // 224 B, one per path in flight (HBM-resident in the wavefront pipeline)
+    double o[3], d[3];          // current ray (d normalised)
+    double T[3], contrib[3];    // throughput prod f_j ; the reference's `contrib` (roulette weight)
+    double L[3];                // radiance accumulated so far
+    double hpos[3], hu, hv;     // hit of the current segment
+    double gdir[3], gcoef[3];   // pending photon gather: direction (= refDir) and factor T*color
+    uint32_t stream;            // Halton sample index = RNG stream
+    int32_t depth;              // -1: slot unused
+    int32_t htri;
+    uint32_t pad;
+};
+enum { ST_CONTINUE = 1, ST_GATHER = 2 };
+
+GI_HD void path_begin(PathRec& p, const Ray& ray, uint32_t sample)
 {
-    Rng rng = rng_make(seed, sample);
-    V3 L = v3(0, 0, 0), T = v3(1, 1, 1), contrib = v3(1, 1, 1);
-    for (int depth = 0; depth <= GI_MAX_DEPTH; depth++) {
-        rng.depth = (uint32_t)depth;
-        HitRec h;
-        if (!trace(S, ray, rng, P_TRACE_ALPHA, h, c)) { L = L + T * ld3(S.ambient); break; }
-        if (c) c->shaded++;
-        float sx = halton_sample(S, 2 + 2 * depth, sample);
-        float sy = halton_sample(S, 3 + 2 * depth, sample);
-        const Mat& m = S.mats[S.tris[h.tri].mat];
-        V3 norm = shading_normal(S, h);
-        V3 color = ld3(m.diffuse);
-        V3 refDir, f = v3(1, 1, 1), i = v3(0, 0, 0);
-        double roughness, offset = GI_SHADOW_BIAS;
-        secondary_ray(ray, m, norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
-        for (int li = 0; li < S.n_light; li++) {
-            const LightD& lt = S.lights[li];
-            double ry = rng_draw(rng, P_LIGHT_Y | ((uint32_t)li << 8));
-            double rx = rng_draw(rng, P_LIGHT_X | ((uint32_t)li << 8));
-            V3 lpos = ld3(lt.pos);
-            V3 so = h.pos + GI_SHADOW_BIAS * norm;
-            V3 lightDir = (lpos + lt.rad * random_unit_vec(rx, ry)) - so;
-            double maxt = len2(lightDir);
-            double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
-            Ray sray = make_ray(so, lightDir);
-            if (visible(S, sray, maxt, rng, (uint32_t)li, c)) {
-                double d = dot(norm, normalize(lpos - h.pos));
-                if (d < 0) d = 0;
-                double l = pow(d, (1.0 / roughness));
-                i = ld3(lt.col) * l * hfrac;
-            }
-        }
-        V3 caustic = depth <= 10 ? gather(S, h.pos, refDir, heap_mem, heap_stride, nullptr, c) : v3(0, 0, 0);
-        double q = comp_max(contrib);
-        if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
-            f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
-            L = L + T * (color * i + ld3(m.emissive) + color * caustic);
-            T = T * f;
-            ray = make_ray(h.pos + offset * norm, refDir);
-        } else {
-            L = L + T * (color * i);
-            break;
+    p.o[0] = ray.o.x; p.o[1] = ray.o.y; p.o[2] = ray.o.z;
+    p.d[0] = ray.d.x; p.d[1] = ray.d.y; p.d[2] = ray.d.z;
+    for (int k = 0; k < 3; k++) { p.T[k] = 1; p.contrib[k] = 1; p.L[k] = 0; }
+    p.stream = sample; p.depth = 0; p.htri = -1; p.pad = 0;
+}
+// stage 1: RayTracer::trace for the current segment.  Miss: L += T*ambient and the path is finished (returns false).
+GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
+{
+    Rng rng = rng_make(seed, p.stream);
+    rng.depth = (uint32_t)p.depth;
+    Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
+    HitRec h;
+    if (!trace(S, ray, rng, P_TRACE_ALPHA, h, c)) {
+        V3 L = ld3(p.L) + ld3(p.T) * ld3(S.ambient);
+        p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+        return false;
+    }
+    p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
+    p.hu = h.u; p.hv = h.v; p.htri = h.tri;
+    return true;
+}
+// stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
+GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
+{
+    Rng rng = rng_make(seed, p.stream);
+    const int depth = p.depth;
+    rng.depth = (uint32_t)depth;
+    if (c) c->shaded++;
+    Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
+    HitRec h;
+    h.pos = ld3(p.hpos); h.u = p.hu; h.v = p.hv; h.tri = p.htri;
+    float sx = halton_sample(S, 2 + 2 * depth, p.stream);
+    float sy = halton_sample(S, 3 + 2 * depth, p.stream);
+    const Mat& m = S.mats[S.tris[h.tri].mat];
+    V3 norm = shading_normal(S, h);
+    V3 color = ld3(m.diffuse);
+    V3 refDir, f = v3(1, 1, 1), i = v3(0, 0, 0), contrib = ld3(p.contrib);
+    double roughness, offset = GI_SHADOW_BIAS;
+    secondary_ray(ray, m, norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
+    for (int li = 0; li < S.n_light; li++) {
+        const LightD& lt = S.lights[li];
+        double ry = rng_draw(rng, P_LIGHT_Y | ((uint32_t)li << 8));
+        double rx = rng_draw(rng, P_LIGHT_X | ((uint32_t)li << 8));
+        V3 lpos = ld3(lt.pos);
+        V3 so = h.pos + GI_SHADOW_BIAS * norm;
+        V3 lightDir = (lpos + lt.rad * random_unit_vec(rx, ry)) - so;
+        double maxt = len2(lightDir);
+        double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
+        Ray sray = make_ray(so, lightDir);
+        if (visible(S, sray, maxt, rng, (uint32_t)li, c)) {
+            double d = dot(norm, normalize(lpos - h.pos));
+            if (d < 0) d = 0;
+            double l = pow(d, (1.0 / roughness));
+            i = ld3(lt.col) * l * hfrac;
         }
     }
-    return L;
+    p.contrib[0] = contrib.x; p.contrib[1] = contrib.y; p.contrib[2] = contrib.z;
+    V3 T = ld3(p.T), L = ld3(p.L);
+    double q = comp_max(contrib);
+    if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
+        f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
+        L = L + T * (color * i + ld3(m.emissive));
+        p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+        int flags = 0;
+        if (depth <= 10 && S.n_pnode > 0) {   // caustic = depth <= 10 ? samplePhotons(minHit, refDir, 32) : 0, include/raytracer.h:258
+            V3 gc = T * color;
+            p.gdir[0] = refDir.x; p.gdir[1] = refDir.y; p.gdir[2] = refDir.z;
+            p.gcoef[0] = gc.x; p.gcoef[1] = gc.y; p.gcoef[2] = gc.z;
+            flags |= ST_GATHER;
+        }
+        T = T * f;
+        p.T[0] = T.x; p.T[1] = T.y; p.T[2] = T.z;
+        Ray next = make_ray(h.pos + offset * norm, refDir);
+        p.o[0] = next.o.x; p.o[1] = next.o.y; p.o[2] = next.o.z;
+        p.d[0] = next.d.x; p.d[1] = next.d.y; p.d[2] = next.d.z;
+        p.depth = depth + 1;
+        if (p.depth <= GI_MAX_DEPTH) flags |= ST_CONTINUE;   // radiance() returns 0 past MAX_DEPTH
+        return flags;
+    }
+    L = L + T * (color * i);
+    p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+    return 0;
+}
+// stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
+GI_HD void stage_gather(const Scene& S, PathRec& p, float* heap_mem, int heap_stride, Counters* c)
+{
+    V3 caustic = gather(S, ld3(p.hpos), ld3(p.gdir), heap_mem, heap_stride, nullptr, c);
+    V3 L = ld3(p.L) + ld3(p.gcoef) * caustic;
+    p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+}
+// the stages back to back for one lane (megakernel, function-level entry points)
+GI_HD V3 radiance_path(const Scene& S, Ray ray, uint32_t sample, uint64_t seed, float* heap_mem, int heap_stride, Counters* c)
+{
+    PathRec p;
+    path_begin(p, ray, sample);
+    for (;;) {
+        if (!stage_trace(S, p, seed, c)) break;
+        const int fl = stage_shade(S, p, seed, c);
+        if (fl & ST_GATHER) stage_gather(S, p, heap_mem, heap_stride, c);
+        if (!(fl & ST_CONTINUE)) break;
+    }
+    return ld3(p.L);
 }
 
 // ------------------------------------------------------------------------------------------------ camera / pixel loop

@@ -28,7 +28,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(GI_BLOCK) void k_render(Scene S, Frame F, void* out, int out_f64, int32_t* out_spp,
                                                      unsigned int* tile_counter, Counters* counters)
 {
-    __shared__ double heap[GI_GATHER_K * GI_BLOCK];
+    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int tiles_x = (F.w + 7) >> 3, tiles_y = (F.local_rows + 7) >> 3;
     const unsigned int n_tiles = (unsigned int)(tiles_x * tiles_y);
@@ -70,6 +70,159 @@ __global__ __launch_bounds__(GI_BLOCK) void k_render(Scene S, Frame F, void* out
     }
 }
 
+// ================================================================================================= wavefront pipeline
+// The frame is rendered in rounds.  In a round every pixel that still wants samples (adaptive loop of RayTracer::run,
+// include/raytracer.h:108-148) starts up to B paths (as many as it is certain to take whatever their variance turns out to
+// be); the paths live as PathRec records in an HBM pool (slot = pixel * B + k) and go through
+//     k_wf_trace  ->  k_wf_shade  ->  k_wf_gather          (one pass per path depth)
+// each kernel working on a compacted queue of slot indices (appended with one atomic per wave from a ballot), so that all
+// 64 lanes of a wave run the same stage; k_wf_accum then folds the finished paths into the per-pixel running mean in sample
+// order.  Per-path arithmetic is the same stage_* code the megakernel runs, so both give the same numbers.
+struct PixRec { double color[3], lastCol[3], var; int32_t samps, s, n, pad; };
+
+__device__ __forceinline__ uint32_t wave_append(unsigned int* counter, bool pred)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
+    base = (unsigned int)__shfl((int)base, leader);
+    return base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// pixel index -> (x, local row): 8x8 tiles so that the 64 lanes of a wave start neighbouring pixels
+__device__ __forceinline__ bool wf_pixel_xy(const Frame& F, uint32_t i, int& x, int& ly)
+{
+    const int tiles_x = (F.w + 7) >> 3;
+    const uint32_t tile = i >> 6, t = i & 63u;
+    x = (int)(tile % (uint32_t)tiles_x) * 8 + (int)(t & 7u);
+    ly = (int)(tile / (uint32_t)tiles_x) * 8 + (int)(t >> 3);
+    return x < F.w && ly < F.local_rows;
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_wf_init(PixRec* pix, uint32_t n_pix)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
+        PixelState ps;
+        pixel_begin(ps);
+        PixRec r;
+        r.color[0] = ps.color.x; r.color[1] = ps.color.y; r.color[2] = ps.color.z;
+        r.lastCol[0] = 0; r.lastCol[1] = 0; r.lastCol[2] = 0;
+        r.var = 0; r.samps = 0; r.s = 0; r.n = 0; r.pad = 0;
+        pix[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_wf_gen(Scene S, Frame F, PixRec* pix, PathRec* pool, uint32_t n_pix, int B)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
+        int x, ly;
+        int n = 0;
+        const bool inside = wf_pixel_xy(F, i, x, ly);
+        int s0 = 0;
+        if (inside) {
+            const int s = pix[i].s, samps = pix[i].samps;
+            if (s < F.max_samples && samps < F.min_samples) {
+                // samples this pixel takes for certain: each one adds 1 to samps or subtracts 1 (include/raytracer.h:143-147)
+                n = min(B, min(F.max_samples - s, F.min_samples - samps));
+                s0 = s;
+            }
+            pix[i].n = n;
+        }
+        const int y = inside ? global_row(F, ly) : 0;
+        for (int k = 0; k < B; k++) {
+            PathRec& p = pool[(size_t)i * B + k];
+            if (k < n) {
+                uint32_t idx;
+                Ray ray = primary_ray(S, F, s0 + k, x, y, idx);
+                path_begin(p, ray, idx);
+            } else
+                p.depth = -1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_wf_trace(Scene S, uint64_t seed, PathRec* pool, const uint32_t* q_in, uint32_t n_in,
+                                                       uint32_t* q_shade, unsigned int* cnt_shade)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        bool hit = false;
+        uint32_t slot = 0;
+        if (i < n_in) {
+            slot = q_in ? q_in[i] : i;
+            PathRec& p = pool[slot];
+            if (p.depth >= 0) hit = stage_trace(S, p, seed, nullptr);
+        }
+        const uint32_t at = wave_append(cnt_shade, hit);
+        if (hit) q_shade[at] = slot;
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_wf_shade(Scene S, uint64_t seed, PathRec* pool, const uint32_t* q_shade, const unsigned int* cnt_shade,
+                                                       uint32_t* q_next, unsigned int* cnt_next, uint32_t* q_gather, unsigned int* cnt_gather)
+{
+    const uint32_t n_in = *cnt_shade;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        int fl = 0;
+        uint32_t slot = 0;
+        if (i < n_in) {
+            slot = q_shade[i];
+            fl = stage_shade(S, pool[slot], seed, nullptr);
+        }
+        const uint32_t a = wave_append(cnt_next, (fl & ST_CONTINUE) != 0);
+        if (fl & ST_CONTINUE) q_next[a] = slot;
+        const uint32_t g = wave_append(cnt_gather, (fl & ST_GATHER) != 0);
+        if (fl & ST_GATHER) q_gather[g] = slot;
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_wf_gather(Scene S, PathRec* pool, const uint32_t* q_gather, const unsigned int* cnt_gather)
+{
+    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
+    const uint32_t n_in = *cnt_gather;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x)
+        stage_gather(S, pool[q_gather[i]], heap + threadIdx.x, GI_BLOCK, nullptr);
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_wf_accum(Frame F, PixRec* pix, const PathRec* pool, uint32_t n_pix, int B, void* out, int out_f64,
+                                                       int32_t* out_spp, unsigned int* n_wanting)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_round = (n_pix + 63u) & ~63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_round; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        bool wants = false;
+        int x, ly;
+        if (i < n_pix && wf_pixel_xy(F, i, x, ly)) {
+            PixRec r = pix[i];
+            PixelState ps;
+            ps.color = ld3(r.color); ps.lastCol = ld3(r.lastCol); ps.var = r.var; ps.samps = r.samps; ps.s = r.s;
+            for (int k = 0; k < r.n; k++) pixel_add_sample(ps, F, ld3(pool[(size_t)i * B + k].L));
+            r.color[0] = ps.color.x; r.color[1] = ps.color.y; r.color[2] = ps.color.z;
+            r.lastCol[0] = ps.lastCol.x; r.lastCol[1] = ps.lastCol.y; r.lastCol[2] = ps.lastCol.z;
+            r.var = ps.var; r.samps = ps.samps; r.s = ps.s; r.n = 0;
+            pix[i] = r;
+            wants = pixel_wants_sample(ps, F);
+            const size_t o = ((size_t)ly * F.w + x);
+            if (out_f64) {
+                double* p = (double*)out + o * 3;
+                p[0] = ps.color.x; p[1] = ps.color.y; p[2] = ps.color.z;
+            } else {
+                float* p = (float*)out + o * 3;
+                p[0] = (float)ps.color.x; p[1] = (float)ps.color.y; p[2] = (float)ps.color.z;
+            }
+            if (out_spp) out_spp[o] = ps.s;
+        }
+        (void)wave_append(n_wanting, wants);
+    }
+}
+
 __global__ __launch_bounds__(GI_BLOCK) void k_trace(Scene S, int n, const double* rays, int32_t* hit, int32_t* ent, double* res)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,7 +257,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_visible(Scene S, int n, const doub
 
 __global__ __launch_bounds__(GI_BLOCK) void k_gather(Scene S, int n, const double* q, double* res3, int32_t* n_cand)
 {
-    __shared__ double heap[GI_GATHER_K * GI_BLOCK];
+    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double* p = q + (size_t)i * 6;
@@ -116,7 +269,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_gather(Scene S, int n, const doubl
 
 __global__ __launch_bounds__(GI_BLOCK) void k_radiance(Scene S, int n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3)
 {
-    __shared__ double heap[GI_GATHER_K * GI_BLOCK];
+    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double* r = rays + (size_t)i * 6;
@@ -198,6 +351,14 @@ struct gi_ctx {
     DevBuf<uint16_t> d_htable;
     DevBuf<unsigned int> d_tile_counter;
     DevBuf<Counters> d_counters;
+    // wavefront pipeline workspaces (grown on demand, kept between frames)
+    DevBuf<PathRec> d_pool;
+    DevBuf<PixRec> d_pix;
+    DevBuf<uint32_t> d_q[4];          // trace ping, trace pong, shade, gather
+    DevBuf<unsigned int> d_wfcnt;     // [0] shade, [1] next, [2] gather, [3] pixels still wanting samples
+    unsigned int* h_wfcnt = nullptr;  // pinned host mirror of d_wfcnt
+    int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
+    size_t pool_slots_max = (size_t)16 << 20;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0;
     int last_launches = 0;
@@ -253,6 +414,7 @@ void gi_destroy(gi_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->h_wfcnt) (void)hipHostFree(c->h_wfcnt);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -314,17 +476,15 @@ int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
 
 int gi_local_rows(const gi_render_params* p) { return local_rows(p); }
 
-int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
+static int grid_for(gi_ctx* c, const void* kernel, size_t dyn_lds = 0)
 {
-    if (!c || !d_out) return GI_E_INVALID;
-    if (!c->have_scene) return fail(c, GI_E_STATE, "render: no scene uploaded");
-    Frame F;
-    std::string ferr;
-    if (!make_frame(p, F, ferr)) return fail(c, GI_E_INVALID, ferr);
-    if (cancel && *cancel) return fail(c, GI_E_CANCELLED, "render: cancelled");
-    HIP_TRY(c, hipSetDevice(c->device));
-    c->last_ms = 0; c->last_launches = 0;
-    if (F.local_rows == 0) return GI_OK;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, GI_BLOCK, dyn_lds) != hipSuccess || per_cu <= 0) per_cu = 2;
+    return c->n_cu * per_cu;
+}
+
+static int render_megakernel(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp)
+{
     HIP_TRY(c, hipMemsetAsync(c->d_tile_counter.p, 0, sizeof(unsigned int), c->stream));
     if (c->count_enabled) HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(Counters), c->stream));
     const int grid = c->n_cu * 2;
@@ -336,6 +496,100 @@ int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->last_launches = 1;
+    return GI_OK;
+}
+
+static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
+{
+    const uint32_t tiles = (uint32_t)(((F.w + 7) >> 3) * ((F.local_rows + 7) >> 3));
+    const uint32_t n_pix = tiles * 64u;
+    int B = (int)std::min<size_t>(32, std::max<size_t>(1, c->pool_slots_max / n_pix));
+    B = std::max(1, std::min(B, std::max(F.max_samples, 1)));
+    const size_t slots = (size_t)n_pix * (size_t)B;
+    if (slots > 0xfffffff0ull) return fail(c, GI_E_INVALID, "render: frame too large for 32-bit path slots");
+    if (c->d_pool.n < slots) HIP_TRY(c, c->d_pool.alloc(slots));
+    if (c->d_pix.n < n_pix) HIP_TRY(c, c->d_pix.alloc(n_pix));
+    for (int k = 0; k < 4; k++) if (c->d_q[k].n < slots) HIP_TRY(c, c->d_q[k].alloc(slots));
+    if (!c->d_wfcnt.p) HIP_TRY(c, c->d_wfcnt.alloc(4));
+    if (!c->h_wfcnt) HIP_TRY(c, hipHostMalloc((void**)&c->h_wfcnt, 4 * sizeof(unsigned int), hipHostMallocDefault));
+    static int g_init = 0, g_gen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0;
+    if (!g_trace) {
+        g_init = grid_for(c, (const void*)k_wf_init); g_gen = grid_for(c, (const void*)k_wf_gen); g_trace = grid_for(c, (const void*)k_wf_trace);
+        g_shade = grid_for(c, (const void*)k_wf_shade); g_gather = grid_for(c, (const void*)k_wf_gather); g_accum = grid_for(c, (const void*)k_wf_accum);
+    }
+    hipStream_t st = c->stream;
+    PathRec* pool = c->d_pool.p;
+    unsigned int* cnt = c->d_wfcnt.p;
+    int launches = 0;
+    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(k_wf_init, dim3(g_init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
+    launches++;
+    // 0 samples per pixel still has to write the initial colour: run the accumulate step once in that case
+    bool any = F.max_samples > 0 && F.min_samples > 0;
+    if (!any) {
+        HIP_TRY(c, hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_wf_accum, dim3(g_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, pool, n_pix, B, d_out, out_is_f64, d_spp, cnt + 3);
+        launches++;
+    }
+    while (any) {
+        if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
+        hipLaunchKernelGGL(k_wf_gen, dim3(g_gen), dim3(GI_BLOCK), 0, st, c->S, F, c->d_pix.p, pool, n_pix, B);
+        launches++;
+        const uint32_t* q_in = nullptr;
+        uint32_t n_in = (uint32_t)slots;
+        int ping = 0;
+        for (int depth = 0; depth <= GI_MAX_DEPTH && n_in > 0; depth++) {
+            HIP_TRY(c, hipMemsetAsync(cnt, 0, 3 * sizeof(unsigned int), st));
+            uint32_t* q_next = c->d_q[ping].p;
+            hipLaunchKernelGGL(k_wf_trace, dim3(g_trace), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, q_in, n_in, c->d_q[2].p, cnt + 0);
+            hipLaunchKernelGGL(k_wf_shade, dim3(g_shade), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_q[2].p, cnt + 0, q_next, cnt + 1, c->d_q[3].p, cnt + 2);
+            if (c->S.n_pnode > 0) { hipLaunchKernelGGL(k_wf_gather, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_q[3].p, cnt + 2); launches++; }
+            launches += 2;
+            HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt, cnt, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            n_in = c->h_wfcnt[1];
+            q_in = q_next;
+            ping ^= 1;
+        }
+        HIP_TRY(c, hipMemsetAsync(cnt + 3, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_wf_accum, dim3(g_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, pool, n_pix, B, d_out, out_is_f64, d_spp, cnt + 3);
+        launches++;
+        HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt + 3, cnt + 3, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        any = c->h_wfcnt[3] > 0;
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    c->last_launches = launches;
+    return GI_OK;
+}
+
+int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
+{
+    if (!c || !d_out) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "render: no scene uploaded");
+    Frame F;
+    std::string ferr;
+    if (!make_frame(p, F, ferr)) return fail(c, GI_E_INVALID, ferr);
+    if (cancel && *cancel) return fail(c, GI_E_CANCELLED, "render: cancelled");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->last_ms = 0; c->last_launches = 0;
+    if (F.local_rows == 0) return GI_OK;
+    if (c->render_mode == 1 || c->count_enabled) return render_megakernel(c, F, d_out, out_is_f64, d_spp);
+    return render_wavefront(c, F, d_out, out_is_f64, d_spp, cancel);
+}
+
+int gi_set_render_mode(gi_ctx* c, int mode)
+{
+    if (!c || (mode != 0 && mode != 1)) return GI_E_INVALID;
+    c->render_mode = mode;
+    return GI_OK;
+}
+
+int gi_set_pool_slots(gi_ctx* c, int64_t slots)
+{
+    if (!c || slots < 64) return GI_E_INVALID;
+    c->pool_slots_max = (size_t)slots;
     return GI_OK;
 }
 

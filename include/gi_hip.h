@@ -93,6 +93,11 @@ int gi_local_rows(const gi_render_params*);
 int gi_render_device(gi_ctx*, const gi_render_params*, void* d_out_lin, int out_is_f64, int32_t* d_out_spp, volatile const int* cancel);
 /* Same, result copied to HOST memory (what a Qt-side caller wants). */
 int gi_render_host(gi_ctx*, const gi_render_params*, void* h_out_lin, int out_is_f64, int32_t* h_out_spp, volatile const int* cancel);
+/* Two implementations of the same arithmetic: 0 = wavefront pipeline (default: trace / shade / gather kernels over compacted
+ * path queues in HBM), 1 = megakernel (one lane keeps one pixel, whole path in registers).  Same numbers either way.        */
+int gi_set_render_mode(gi_ctx*, int mode);
+/* Upper bound on paths in flight in the wavefront pipeline (224 B each; default 16 Mi).                                      */
+int gi_set_pool_slots(gi_ctx*, int64_t slots);
 /* Device time in ms of the render kernel(s) of the last gi_render_* call, measured with hipEvents on the launch stream. */
 int gi_last_render_ms(gi_ctx*, float* ms, int32_t* n_launches);
 /* Work counters of the last render (when enabled with gi_set_counters(ctx,1)): node visits in trace, node visits in

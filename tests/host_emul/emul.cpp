@@ -76,7 +76,7 @@ int emul_visible(Emul* e, int n, const double* q, int32_t* vis)
 }
 int emul_gather(Emul* e, int n, const double* q, double* res3, int32_t* n_cand)
 {
-    double heap[GI_GATHER_K * 4];
+    float heap[GI_GATHER_K * 4];
     for (int i = 0; i < n; i++) {
         const double* p = q + (size_t)i * 6;
         int nc = 0;
@@ -88,7 +88,7 @@ int emul_gather(Emul* e, int n, const double* q, double* res3, int32_t* n_cand)
 }
 int emul_radiance(Emul* e, int n, const double* rays, const uint32_t* stream, uint64_t seed, double* out3)
 {
-    double heap[GI_GATHER_K];
+    float heap[GI_GATHER_K];
     for (int i = 0; i < n; i++) {
         const double* r = rays + (size_t)i * 6;
         Ray ray = make_ray_exact(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]));
@@ -101,7 +101,7 @@ int emul_render(Emul* e, const gi_render_params* p, double* out, int32_t* out_sp
 {
     Frame F;
     if (!make_frame(p, F, e->err)) return GI_E_INVALID;
-    double heap[GI_GATHER_K];
+    float heap[GI_GATHER_K];
     Counters c;
     memset(&c, 0, sizeof c);
     const int tiles_x = (F.w + 7) >> 3, tiles_y = (F.local_rows + 7) >> 3;

@@ -90,6 +90,39 @@ def check_render(rt, scene, w, h, spp, photons, adaptive=False):
     return rmse, img, ref["lin"]
 
 
+def check_gather_float_ties(rt_factory):
+    """Photons whose squared distances to the query agree to float precision around rank 32: the float-key heap cannot
+    separate them, the exact pass must.  40 photons on a ray from the query point, spacing 1e-9."""
+    s = gi.Scene()
+    m = s.add_material(1.0, 1.0, 1.0, (1, 1, 1))
+    s.add_triangles(np.array([[[0, 0, 0], [4, 0, 0], [0, 0, 4]], [[4, 0, 0], [4, 0, 4], [0, 0, 4]], [[0, 4, 0], [4, 4, 0], [0, 4, 4]]], float), mat_idx=[m] * 3)
+    s.add_light((2, 3, 2), (1, 1, 1), .05)
+    s.rebuild()
+    rs = np.random.RandomState(5)
+    n = 40
+    q = np.array([1.0, 1.0, 1.0]) * 2.0 ** -3
+    # 40 photons on a shell of radius 2^-20 (1 + k 2^-30) around q: squared distances differ by ~2e-9 relative, far below
+    # float resolution; 10 clearly nearer ones put rank 32 inside that group.  The whole cluster (radius 1e-6) lies inside
+    # the +-1e-5 neighbourhood of the leaf that contains q, so all 50 are candidates.
+    u = rs.randn(n, 3); u /= np.linalg.norm(u, axis=1)[:, None]
+    pos = q + u * (2.0 ** -20 * (1 + rs.permutation(n) * 2.0 ** -30))[:, None]
+    d = rs.randn(n, 3); d /= np.linalg.norm(d, axis=1)[:, None]
+    ph = np.concatenate([pos, d, rs.rand(n, 3)], axis=1)
+    un = rs.randn(10, 3); un /= np.linalg.norm(un, axis=1)[:, None]
+    near = np.concatenate([q + un * 2.0 ** -21 * (1 + rs.rand(10, 1)* 0.5), d[:10], rs.rand(10, 3)], axis=1)
+    ph = np.concatenate([near, ph])
+    rt = rt_factory().setScene(s)
+    s.build_photon_map(ph)
+    rt.upload_photon_map()
+    o = oracle_for(s)
+    o.set_photons(ph).build_photon_map()
+    qq = np.array([[*q, 0.3, 0.5, 0.8]])
+    got, nc = rt.samplePhotons(qq)
+    ref, nco = o.gather(qq)
+    assert nc[0] == nco[0] == 50
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+
+
 def check_stripes(rt, scene, w, h, spp, world, stripe_h):
     """Row-stripe sharding: rendering the stripes of every rank and interleaving them gives the single-GPU frame exactly."""
     full = rt.run(w, h, min_samples=spp, max_samples=spp)

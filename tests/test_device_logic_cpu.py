@@ -59,3 +59,7 @@ def test_render_matches_oracle(setup, adaptive):
 def test_stripe_sharding_is_exact(setup):
     name, scene, rt, fx = setup
     pc.check_stripes(rt, scene, 24, 21, 2, world=3, stripe_h=4)
+
+
+def test_gather_resolves_float_key_ties_exactly():
+    pc.check_gather_float_ties(el.EmulRayTracer)

@@ -52,11 +52,32 @@ def test_emission_identical_to_oracle(setup):
     pc.check_emission(rt, scene, 3000)
 
 
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
 @pytest.mark.parametrize("adaptive", [False, True])
-def test_render_matches_oracle(setup, adaptive):
+def test_render_matches_oracle(setup, adaptive, mode):
     name, scene, rt, fx = setup
-    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, adaptive)
+    rt.set_render_mode(mode)
+    try:
+        rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, adaptive)
+    finally:
+        rt.set_render_mode("wavefront")
     assert rmse < 1e-9, rmse      # far inside the 1e-4 contract: any larger value means a diverged path
+
+
+def test_wavefront_small_pool_many_rounds(setup):
+    """Few path slots -> many rounds of few samples each: the same frame as with one big round."""
+    name, scene, rt, fx = setup
+    a = rt.run(40, 30, min_samples=6, max_samples=6)
+    rt.set_pool_slots(40 * 32 * 2)      # 2 paths per (padded) pixel
+    try:
+        b = rt.run(40, 30, min_samples=6, max_samples=6)
+    finally:
+        rt.set_pool_slots(16 << 20)
+    assert np.array_equal(a, b)
+
+
+def test_gather_resolves_float_key_ties_exactly():
+    pc.check_gather_float_ties(lambda: gi.RayTracer(0))
 
 
 def test_radiance_entry_matches_oracle(setup):
