@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--photons", type=int, default=200000)
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (-1: sized for ~20 s, 0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--mode", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--mode", default="wavefront", choices=["wavefront", "rounds", "megakernel"])
     args = ap.parse_args()
 
     import torch

@@ -325,7 +325,7 @@ class RayTracer:
 
     def set_render_mode(self, mode):
         """'wavefront' (default) or 'megakernel': two schedules of the same per-path arithmetic."""
-        self._check(self.L.gi_set_render_mode(self.h, {"wavefront": 0, "megakernel": 1}[mode]), "set_render_mode")
+        self._check(self.L.gi_set_render_mode(self.h, {"wavefront": 0, "megakernel": 1, "rounds": 2}[mode]), "set_render_mode")
 
     def set_pool_slots(self, slots):
         self._check(self.L.gi_set_pool_slots(self.h, int(slots)), "set_pool_slots")

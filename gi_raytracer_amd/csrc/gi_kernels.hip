@@ -223,6 +223,146 @@ __global__ __launch_bounds__(GI_BLOCK) void k_wf_accum(Frame F, PixRec* pix, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------- streaming variant (fixed spp)
+// When min_samples == max_samples every pixel takes exactly spp samples, so samples can be started in any order as long as
+// they are folded into the running mean in sample order.  Path slots are refilled with the next unstarted sample as soon as
+// their path ends (path regeneration): every pass works on a full pool and the straggler tail is paid once per frame, not
+// once per round.  Finished paths write their radiance to Lbuf[sample]; k_st_accum folds Lbuf per pixel in sample order.
+// sample id = s * n_pix + i  (i = 8x8-tile-ordered pixel index): consecutive ids are neighbouring pixels of one sample index.
+struct StreamCtl {
+    unsigned long long next_sample;   // next sample id to start
+    unsigned int n_new, n_cont, n_shade, n_gather, n_free, pad;
+};
+
+__device__ __forceinline__ void st_finish(const PathRec& p, uint32_t slot, const unsigned long long* slot_sample, unsigned long long sample0,
+                                          double* lbuf, uint32_t* q_free, unsigned int* n_free, bool finished)
+{
+    if (finished) {
+        const unsigned long long id = slot_sample[slot] - sample0;
+        lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
+    }
+    const uint32_t at = wave_append(n_free, finished);
+    if (finished) q_free[at] = slot;
+}
+
+// refill free slots (q_free == nullptr: slots 0..n_free-1) with the next samples; new paths go to q_new
+__global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec* pool, unsigned long long* slot_sample, const uint32_t* q_free, uint32_t n_free,
+                                                      unsigned long long sample_end, uint32_t n_pix, StreamCtl* ctl, uint32_t* q_new)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_free; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        const bool want = i < n_free;
+        // one atomic per wave: the lanes of a wave get consecutive sample ids (neighbouring pixels)
+        const unsigned long long mask = __ballot(want);
+        unsigned long long base = 0;
+        const int leader = __ffsll((long long)mask) - 1;
+        if (mask && (int)lane == leader) base = atomicAdd(&ctl->next_sample, (unsigned long long)__popcll(mask));
+        base = (unsigned long long)__shfl((long long)base, leader < 0 ? 0 : leader);
+        unsigned long long id = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        bool started = false;
+        uint32_t slot = 0;
+        if (want) {
+            int x = 0, ly = 0;
+            // padding pixels of partial 8x8 tiles own sample ids but no work: skip to the next id (rare, per-lane atomic)
+            while (id < sample_end && !wf_pixel_xy(F, (uint32_t)(id % n_pix), x, ly)) id = atomicAdd(&ctl->next_sample, 1ull);
+            if (id < sample_end) {
+                slot = q_free ? q_free[i] : i;
+                slot_sample[slot] = id;
+                uint32_t idx;
+                Ray ray = primary_ray(S, F, (int)(id / n_pix), x, global_row(F, ly), idx);
+                path_begin(pool[slot], ray, idx);
+                started = true;
+            }
+        }
+        const uint32_t at = wave_append(&ctl->n_new, started);
+        if (started) q_new[at] = slot;
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+                                                       const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
+                                                       uint32_t* q_shade, uint32_t* q_free, double* lbuf)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_in = n_a + n_b;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        bool hit = false, fin = false;
+        uint32_t slot = 0;
+        if (i < n_in) {
+            slot = i < n_a ? q_a[i] : q_b[i - n_a];
+            PathRec& p = pool[slot];
+            if (p.depth > GI_MAX_DEPTH) fin = true;            // radiance() returns 0 past MAX_DEPTH
+            else { hit = stage_trace(S, p, seed, nullptr); fin = !hit; }
+        }
+        const uint32_t at = wave_append(&ctl->n_shade, hit);
+        if (hit) q_shade[at] = slot;
+        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free, &ctl->n_free, fin);
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+                                                       const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
+{
+    const uint32_t n_in = ctl->n_shade;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        int fl = 0;
+        bool valid = i < n_in;
+        uint32_t slot = 0;
+        if (valid) {
+            slot = q_shade[i];
+            fl = stage_shade(S, pool[slot], seed, nullptr);
+        }
+        // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
+        const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
+        const uint32_t a = wave_append(&ctl->n_cont, cont);
+        if (cont) q_cont[a] = slot;
+        const uint32_t g = wave_append(&ctl->n_gather, (fl & ST_GATHER) != 0);
+        if (fl & ST_GATHER) q_gather[g] = slot;
+        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free, &ctl->n_free, valid && !cont);
+    }
+}
+
+__global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, const uint32_t* q_gather, const StreamCtl* ctl)
+{
+    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
+    const uint32_t n_in = ctl->n_gather;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x)
+        stage_gather(S, pool[q_gather[i]], heap + threadIdx.x, GI_BLOCK, nullptr);
+}
+
+// fold samples [s0, s0 + ns) of every pixel into its running mean, in sample order (include/raytracer.h:131-147)
+__global__ __launch_bounds__(GI_BLOCK) void k_st_accum(Frame F, PixRec* pix, const double* lbuf, uint32_t n_pix, int ns, void* out, int out_f64, int32_t* out_spp)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
+        int x, ly;
+        if (!wf_pixel_xy(F, i, x, ly)) continue;
+        PixRec r = pix[i];
+        PixelState ps;
+        ps.color = ld3(r.color); ps.lastCol = ld3(r.lastCol); ps.var = r.var; ps.samps = r.samps; ps.s = r.s;
+        for (int k = 0; k < ns; k++) {
+            const double* l = lbuf + ((size_t)k * n_pix + i) * 3;
+            pixel_add_sample(ps, F, v3(l[0], l[1], l[2]));
+        }
+        r.color[0] = ps.color.x; r.color[1] = ps.color.y; r.color[2] = ps.color.z;
+        r.lastCol[0] = ps.lastCol.x; r.lastCol[1] = ps.lastCol.y; r.lastCol[2] = ps.lastCol.z;
+        r.var = ps.var; r.samps = ps.samps; r.s = ps.s;
+        pix[i] = r;
+        const size_t o = ((size_t)ly * F.w + x);
+        if (out_f64) {
+            double* p = (double*)out + o * 3;
+            p[0] = ps.color.x; p[1] = ps.color.y; p[2] = ps.color.z;
+        } else {
+            float* p = (float*)out + o * 3;
+            p[0] = (float)ps.color.x; p[1] = (float)ps.color.y; p[2] = (float)ps.color.z;
+        }
+        if (out_spp) out_spp[o] = ps.s;
+    }
+}
+
 __global__ __launch_bounds__(GI_BLOCK) void k_trace(Scene S, int n, const double* rays, int32_t* hit, int32_t* ent, double* res)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,6 +497,12 @@ struct gi_ctx {
     DevBuf<uint32_t> d_q[4];          // trace ping, trace pong, shade, gather
     DevBuf<unsigned int> d_wfcnt;     // [0] shade, [1] next, [2] gather, [3] pixels still wanting samples
     unsigned int* h_wfcnt = nullptr;  // pinned host mirror of d_wfcnt
+    DevBuf<double> d_lbuf;            // streaming variant: per-sample radiance of the current chunk
+    DevBuf<unsigned long long> d_slot_sample;
+    DevBuf<uint32_t> d_qs[6];         // streaming queues: new, cont ping, cont pong, shade, gather, free ping/pong share [5] + d_q
+    DevBuf<StreamCtl> d_ctl;
+    StreamCtl* h_ctl = nullptr;
+    size_t lbuf_bytes_max = (size_t)16 << 30;
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
     size_t pool_slots_max = (size_t)16 << 20;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -415,6 +561,7 @@ void gi_destroy(gi_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->h_wfcnt) (void)hipHostFree(c->h_wfcnt);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -547,6 +694,17 @@ static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             launches += 2;
             HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt, cnt, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
+            if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[wf] depth %d in %u shade %u next %u gather %u\n", depth, n_in, c->h_wfcnt[0], c->h_wfcnt[1], c->h_wfcnt[2]);
+            if (getenv("GI_DEBUG_WF") && depth == 40 && c->h_wfcnt[1] > 0) {
+                std::vector<uint32_t> q(std::min<uint32_t>(c->h_wfcnt[1], 12));
+                (void)hipMemcpy(q.data(), q_next, q.size() * 4, hipMemcpyDeviceToHost);
+                for (uint32_t sl : q) {
+                    PathRec r;
+                    (void)hipMemcpy(&r, pool + sl, sizeof r, hipMemcpyDeviceToHost);
+                    fprintf(stderr, "[wf] straggler slot %u o=(%.17g %.17g %.17g) d=(%.17g %.17g %.17g) T=(%g %g %g) contrib=(%g %g %g) tri=%d hpos=(%g %g %g)\n", sl, r.o[0], r.o[1], r.o[2], r.d[0], r.d[1], r.d[2],
+                            r.T[0], r.T[1], r.T[2], r.contrib[0], r.contrib[1], r.contrib[2], r.htri, r.hpos[0], r.hpos[1], r.hpos[2]);
+                }
+            }
             n_in = c->h_wfcnt[1];
             q_in = q_next;
             ping ^= 1;
@@ -557,6 +715,95 @@ static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt + 3, cnt + 3, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         any = c->h_wfcnt[3] > 0;
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    c->last_launches = launches;
+    return GI_OK;
+}
+
+static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
+{
+    const uint32_t tiles = (uint32_t)(((F.w + 7) >> 3) * ((F.local_rows + 7) >> 3));
+    const uint32_t n_pix = tiles * 64u;
+    const int spp = F.max_samples;
+    const uint32_t P = (uint32_t)std::min<size_t>(c->pool_slots_max, (size_t)n_pix * (size_t)spp);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)));
+    if (c->d_pool.n < P) HIP_TRY(c, c->d_pool.alloc(P));
+    if (c->d_slot_sample.n < P) HIP_TRY(c, c->d_slot_sample.alloc(P));
+    if (c->d_pix.n < n_pix) HIP_TRY(c, c->d_pix.alloc(n_pix));
+    for (int k = 0; k < 6; k++) if (c->d_qs[k].n < P) HIP_TRY(c, c->d_qs[k].alloc(P));
+    if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
+    if (c->d_lbuf.n < (size_t)n_pix * chunk * 3) HIP_TRY(c, c->d_lbuf.alloc((size_t)n_pix * chunk * 3));
+    if (!c->d_ctl.p) HIP_TRY(c, c->d_ctl.alloc(1));
+    if (!c->h_ctl) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, sizeof(StreamCtl), hipHostMallocDefault));
+    static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0;
+    if (!g_trace) {
+        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace);
+        g_shade = grid_for(c, (const void*)k_st_shade); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum);
+    }
+    hipStream_t st = c->stream;
+    PathRec* pool = c->d_pool.p;
+    StreamCtl* ctl = c->d_ctl.p;
+    uint32_t* q_new = c->d_qs[0].p;
+    uint32_t* q_cont[2] = {c->d_qs[1].p, c->d_qs[2].p};
+    uint32_t* q_shade = c->d_qs[3].p;
+    uint32_t* q_gather = c->d_qs[4].p;
+    uint32_t* q_free[2] = {c->d_qs[5].p, c->d_q[0].p};
+    int launches = 0;
+    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(k_wf_init, dim3(g_init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
+    launches++;
+    for (int s0 = 0; s0 < spp; s0 += chunk) {
+        const int ns = std::min(chunk, spp - s0);
+        const unsigned long long sample0 = (unsigned long long)s0 * n_pix, sample_end = (unsigned long long)(s0 + ns) * n_pix;
+        StreamCtl h0;
+        memset(&h0, 0, sizeof h0);
+        h0.next_sample = sample0;
+        *c->h_ctl = h0;
+        HIP_TRY(c, hipMemcpyAsync(ctl, c->h_ctl, sizeof(StreamCtl), hipMemcpyHostToDevice, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        // pass 0: every slot is free
+        uint32_t n_free = P, n_cont = 0;
+        const uint32_t* qf = nullptr;
+        int ping = 0;
+        bool samples_left = true;
+        for (;;) {
+            if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
+            if (samples_left && n_free > 0) {
+                hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_free, sample_end, n_pix, ctl, q_new);
+                launches++;
+            }
+            // the trace pass needs n_new on the host for its bounds: read it back (regen is cheap, this is the only extra sync)
+            HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            const uint32_t n_new = c->h_ctl->n_new;
+            samples_left = c->h_ctl->next_sample < sample_end;
+            if (n_new + n_cont == 0) break;
+            // reset the per-pass counters (next_sample is preserved)
+            StreamCtl hz = *c->h_ctl;
+            hz.n_new = 0; hz.n_cont = 0; hz.n_shade = 0; hz.n_gather = 0; hz.n_free = 0;
+            *c->h_ctl = hz;
+            HIP_TRY(c, hipMemcpyAsync(ctl, c->h_ctl, sizeof(StreamCtl), hipMemcpyHostToDevice, st));
+            uint32_t* qfree_out = q_free[ping];
+            uint32_t* qcont_out = q_cont[ping];
+            const uint32_t* qcont_in = q_cont[ping ^ 1];
+            hipLaunchKernelGGL(k_st_trace, dim3(g_trace), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+                               q_shade, qfree_out, c->d_lbuf.p);
+            hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, qcont_out, q_gather,
+                               qfree_out, c->d_lbuf.p);
+            launches += 2;
+            if (c->S.n_pnode > 0) { hipLaunchKernelGGL(k_st_gather, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl); launches++; }
+            HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+            n_cont = c->h_ctl->n_cont;
+            n_free = c->h_ctl->n_free;
+            qf = qfree_out;
+            ping ^= 1;
+            if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u next %llu/%llu\n", n_new, n_cont, n_free, c->h_ctl->n_gather, c->h_ctl->next_sample, sample_end);
+        }
+        hipLaunchKernelGGL(k_st_accum, dim3(g_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, ns, d_out, out_is_f64, d_spp);
+        launches++;
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, st));
@@ -576,12 +823,14 @@ int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_
     c->last_ms = 0; c->last_launches = 0;
     if (F.local_rows == 0) return GI_OK;
     if (c->render_mode == 1 || c->count_enabled) return render_megakernel(c, F, d_out, out_is_f64, d_spp);
+    // fixed sample count: streaming pool with path regeneration; adaptive sampling: synchronous rounds (sample-order decisions)
+    if (c->render_mode == 0 && F.min_samples == F.max_samples && F.max_samples > 0) return render_streaming(c, F, d_out, out_is_f64, d_spp, cancel);
     return render_wavefront(c, F, d_out, out_is_f64, d_spp, cancel);
 }
 
 int gi_set_render_mode(gi_ctx* c, int mode)
 {
-    if (!c || (mode != 0 && mode != 1)) return GI_E_INVALID;
+    if (!c || mode < 0 || mode > 2) return GI_E_INVALID;
     c->render_mode = mode;
     return GI_OK;
 }

@@ -93,8 +93,9 @@ int gi_local_rows(const gi_render_params*);
 int gi_render_device(gi_ctx*, const gi_render_params*, void* d_out_lin, int out_is_f64, int32_t* d_out_spp, volatile const int* cancel);
 /* Same, result copied to HOST memory (what a Qt-side caller wants). */
 int gi_render_host(gi_ctx*, const gi_render_params*, void* h_out_lin, int out_is_f64, int32_t* h_out_spp, volatile const int* cancel);
-/* Two implementations of the same arithmetic: 0 = wavefront pipeline (default: trace / shade / gather kernels over compacted
- * path queues in HBM), 1 = megakernel (one lane keeps one pixel, whole path in registers).  Same numbers either way.        */
+/* Schedules of the same per-path arithmetic: 0 = wavefront pipeline (default: trace / shade / gather kernels over compacted
+ * path queues in HBM; fixed-spp frames refill finished slots with new samples, adaptive frames run in synchronous rounds),
+ * 1 = megakernel (one lane keeps one pixel, whole path in registers), 2 = wavefront in synchronous rounds always.            */
 int gi_set_render_mode(gi_ctx*, int mode);
 /* Upper bound on paths in flight in the wavefront pipeline (224 B each; default 16 Mi).                                      */
 int gi_set_pool_slots(gi_ctx*, int64_t slots);

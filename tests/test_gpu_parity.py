@@ -52,7 +52,7 @@ def test_emission_identical_to_oracle(setup):
     pc.check_emission(rt, scene, 3000)
 
 
-@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+@pytest.mark.parametrize("mode", ["wavefront", "rounds", "megakernel"])
 @pytest.mark.parametrize("adaptive", [False, True])
 def test_render_matches_oracle(setup, adaptive, mode):
     name, scene, rt, fx = setup
@@ -70,10 +70,13 @@ def test_wavefront_small_pool_many_rounds(setup):
     a = rt.run(40, 30, min_samples=6, max_samples=6)
     rt.set_pool_slots(40 * 32 * 2)      # 2 paths per (padded) pixel
     try:
-        b = rt.run(40, 30, min_samples=6, max_samples=6)
+        b = rt.run(40, 30, min_samples=6, max_samples=6)           # streaming: the pool is refilled ~3x
+        rt.set_render_mode("rounds")
+        c = rt.run(40, 30, min_samples=6, max_samples=6)           # synchronous rounds of 2 samples
     finally:
         rt.set_pool_slots(16 << 20)
-    assert np.array_equal(a, b)
+        rt.set_render_mode("wavefront")
+    assert np.array_equal(a, b) and np.array_equal(a, c)
 
 
 def test_gather_resolves_float_key_ties_exactly():
