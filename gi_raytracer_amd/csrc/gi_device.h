@@ -51,10 +51,15 @@ struct TriGeom {            // 80 B: what a ray-triangle test needs
 struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; };  // 96 B, read once per shaded hit
 struct Mat { double roughness, opacity, ior, diffuse[3], emissive[3]; };
 struct LightD { double pos[3], col[3], rad, dir[3], angle; };
-struct PNode {              // 64 B: photon octree node, pre-order with skip links; photons are stored in leaf order
-    double bmin[3], bmax[3];
-    int32_t skip, first, count, is_leaf;
+struct alignas(128) PNode { // 128 B: photon octree node; the 8 children of a node are 8 consecutive records
+    double bmin[3], bmax[3];// node box: PhotonMap::Node::getBounds checks contains() at every level
+    double mid[3];          // inner nodes: lower corner of child 7 = the split point the reference computes
+    int32_t first_child;    // record index of child 0, or -1 for a leaf
+    int32_t nb_off, nb_cnt; // leaves: candidate photon ranges [nb_off, nb_off + nb_cnt) in Scene::pranges
+    int32_t nb_photons;     // leaves: total photons in those ranges (= what PhotonMap::getInRange returns for this leaf)
+    int32_t pad[10];
 };
+struct PRange { int32_t first, count; };   // photons are stored leaf by leaf in the reference's DFS order
 struct HaltonDim { uint32_t P, n, off; float scale; };
 
 struct Scene {
@@ -65,6 +70,7 @@ struct Scene {
     const Mat* mats;
     const LightD* lights;
     const PNode* pnodes;
+    const PRange* pranges;
     const double* ph_pos;     // [n_photon][3] leaf order
     const double* ph_dircol;  // [n_photon][6] leaf order
     const HaltonDim* hdims;   // [256]
@@ -424,71 +430,59 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride
     if (n_cand_out) *n_cand_out = 0;
     if (c) c->gathers++;
     if (S.n_pnode <= 0) return res;
-    // PhotonMap::Node::getBounds (include/photonMap.cpp:115-134)
+    // PhotonMap::Node::getBounds (include/photonMap.cpp:115-134): descend to the leaf whose half-open box contains pos.  The
+    // children are the 8 octants around `mid`, so the only child that can contain pos is the one on pos's side of mid on every
+    // axis (x = bit0, z = bit1, y = bit2); its contains() test is still made, because the upper children end at mid + .5*extent,
+    // which may fall an ulp short of the parent's box.
     int32_t node = 0;
-    bool found = true;
-    while (!S.pnodes[node].is_leaf) {
-        int32_t ch = node + 1;
-        int i = 0;
-        for (; i < 8; i++) {
-            const PNode& cn = S.pnodes[ch];
-            if (box_contains(cn.bmin, cn.bmax, pos)) break;
-            ch = cn.skip;
-        }
-        if (i == 8) { found = false; break; }
+    while (S.pnodes[node].first_child >= 0) {
+        const PNode& nd = S.pnodes[node];
+        const int k = (pos.x >= nd.mid[0] ? 1 : 0) | (pos.z >= nd.mid[2] ? 2 : 0) | (pos.y >= nd.mid[1] ? 4 : 0);
+        const int32_t ch = nd.first_child + k;
+        const PNode& cn = S.pnodes[ch];
+        if (!box_contains(cn.bmin, cn.bmax, pos)) return res;   // no child contains pos: box of -inf, nothing is collected
         node = ch;
     }
-    if (!found) return res;  // box of -inf: nothing is collected (root is not a leaf here)
-    double qmin[3], qmax[3];
-    {
-        const PNode& lf = S.pnodes[node];
-        for (int k = 0; k < 3; k++) { qmin[k] = lf.bmin[k] - GI_EPSILON; qmax[k] = lf.bmax[k] + GI_EPSILON; }
-    }
-    if (qmax[0] - qmin[0] <= 0) return res;  // PhotonMap::Node::get, include/photonMap.cpp:73-74
+    // PhotonMap::Node::get (include/photonMap.cpp:71-92) for this leaf's (+-EPSILON) box was run once per leaf when the map was
+    // laid out (gi_layout.h): its result is the list of photon ranges [nb_off, nb_off + nb_cnt)
+    const PNode& lf = S.pnodes[node];
+    const PRange* ranges = S.pranges + lf.nb_off;
+    const int n_ranges = lf.nb_cnt;
+    const int ncand = lf.nb_photons;
+    if (n_cand_out) *n_cand_out = ncand;
+    if (c) c->pcand += (unsigned long long)ncand;
+    if (ncand == 0) return res;
     // pass 1
     Heap h;
     h.hp = heap_mem; h.stride = heap_stride; h.n = 0;
-    int ncand = 0;
     float tau = 0;
-    node = 0;
-    while (node < S.n_pnode) {
-        const PNode& nd = S.pnodes[node];
-        if (node != 0 && !boxes_touch(nd.bmin, nd.bmax, qmin, qmax)) { node = nd.skip; continue; }
-        if (!nd.is_leaf) { node = node + 1; continue; }
-        for (int32_t k = 0; k < nd.count; k++) {
-            const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
+    for (int r = 0; r < n_ranges; r++) {
+        const PRange rg = ranges[r];
+        const double* pp = S.ph_pos + (size_t)rg.first * 3;
+        for (int32_t k = 0; k < rg.count; k++, pp += 3) {
             float key = (float)len2(v3(pp[0], pp[1], pp[2]) - pos);
             if (h.n < GI_GATHER_K) { heap_push(h, key); tau = h.hp[0]; }
             else if (key < tau) { heap_replace_root(h, key); tau = h.hp[0]; }
         }
-        ncand += nd.count;
-        node = nd.skip;
     }
-    if (n_cand_out) *n_cand_out = ncand;
-    if (c) c->pcand += (unsigned long long)ncand;
-    if (ncand == 0) return res;
     const int K = ncand < GI_GATHER_K ? ncand : GI_GATHER_K;
     // pass 2
     V3 s_lt = v3(0, 0, 0), s_eq = v3(0, 0, 0);
     int c_lt = 0, c_eq = 0;
     double r_eq = 0;
-    node = 0;
-    while (node < S.n_pnode) {
-        const PNode& nd = S.pnodes[node];
-        if (node != 0 && !boxes_touch(nd.bmin, nd.bmax, qmin, qmax)) { node = nd.skip; continue; }
-        if (!nd.is_leaf) { node = node + 1; continue; }
-        for (int32_t k = 0; k < nd.count; k++) {
-            const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
+    for (int r = 0; r < n_ranges; r++) {
+        const PRange rg = ranges[r];
+        const double* pp = S.ph_pos + (size_t)rg.first * 3;
+        for (int32_t k = 0; k < rg.count; k++, pp += 3) {
             double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
             float key = (float)d2;
             if (key <= tau) {
-                const double* dc = S.ph_dircol + (size_t)(nd.first + k) * 6;
+                const double* dc = S.ph_dircol + (size_t)(rg.first + k) * 6;
                 V3 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
                 if (key < tau) { s_lt = s_lt + contrib; c_lt++; }
                 else { s_eq = s_eq + contrib; c_eq++; r_eq = d2 > r_eq ? d2 : r_eq; }
             }
         }
-        node = nd.skip;
     }
     const int need = K - c_lt;  // >= 1: the heap root itself is a candidate with key == tau
     double r2;
@@ -500,21 +494,17 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride
         for (int j = 0; j < need; j++) {
             double best = INFINITY;
             V3 bc = v3(0, 0, 0);
-            node = 0;
-            while (node < S.n_pnode) {
-                const PNode& nd = S.pnodes[node];
-                if (node != 0 && !boxes_touch(nd.bmin, nd.bmax, qmin, qmax)) { node = nd.skip; continue; }
-                if (!nd.is_leaf) { node = node + 1; continue; }
-                for (int32_t k = 0; k < nd.count; k++) {
-                    const double* pp = S.ph_pos + (size_t)(nd.first + k) * 3;
+            for (int r = 0; r < n_ranges; r++) {
+                const PRange rg = ranges[r];
+                const double* pp = S.ph_pos + (size_t)rg.first * 3;
+                for (int32_t k = 0; k < rg.count; k++, pp += 3) {
                     double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
                     if ((float)d2 == tau && d2 > last && d2 < best) {
-                        const double* dc = S.ph_dircol + (size_t)(nd.first + k) * 6;
+                        const double* dc = S.ph_dircol + (size_t)(rg.first + k) * 6;
                         best = d2;
                         bc = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
                     }
                 }
-                node = nd.skip;
             }
             if (best == INFINITY) break;   // exact duplicates exhausted the group
             res = res + bc;

@@ -486,6 +486,7 @@ struct gi_ctx {
     DevBuf<Mat> d_mats;
     DevBuf<LightD> d_lights;
     DevBuf<PNode> d_pnodes;
+    DevBuf<PRange> d_pranges;
     DevBuf<double> d_ph_pos, d_ph_dircol;
     DevBuf<HaltonDim> d_hdims;
     DevBuf<uint16_t> d_htable;
@@ -614,9 +615,10 @@ int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
         return GI_OK;
     }
     HIP_TRY(c, c->d_pnodes.upload(H.nodes));
+    HIP_TRY(c, c->d_pranges.upload(H.ranges));
     HIP_TRY(c, c->d_ph_pos.upload(H.pos));
     HIP_TRY(c, c->d_ph_dircol.upload(H.dircol));
-    S.pnodes = c->d_pnodes.p; S.ph_pos = c->d_ph_pos.p; S.ph_dircol = c->d_ph_dircol.p;
+    S.pnodes = c->d_pnodes.p; S.pranges = c->d_pranges.p; S.ph_pos = c->d_ph_pos.p; S.ph_dircol = c->d_ph_dircol.p;
     S.n_pnode = H.n_node; S.n_photon = H.n_photon;
     return GI_OK;
 }

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -30,6 +31,7 @@ struct HostScene {
 };
 struct HostPhotons {
     std::vector<PNode> nodes;
+    std::vector<PRange> ranges;
     std::vector<double> pos, dircol;
     int32_t n_node = 0, n_photon = 0;
 };
@@ -195,30 +197,36 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
     return true;
 }
 
-// photon octree: the input must be pre-order (first child = n+1, each next child where the previous sub-tree ends)
+// photon octree.  Input: the reference's tree in pre-order (first child = n+1, each next child where the previous sub-tree
+// ends).  Output: (1) photons re-ordered leaf by leaf in that DFS order; (2) node records where the 8 children of a node are
+// consecutive, so the descent of PhotonMap::Node::getBounds indexes the child directly; (3) for every leaf the result of
+// PhotonMap::Node::get(leaf box +- EPSILON) (include/photonMap.cpp:50-92) as a list of photon ranges -- the candidate set of a
+// gather depends only on the leaf that contains the query point, so it is computed once per leaf here instead of per query.
 inline bool layout_photons(const gi_photon_map_desc* d, HostPhotons& H, std::string& err)
 {
-    H.nodes.clear(); H.pos.clear(); H.dircol.clear(); H.n_node = 0; H.n_photon = 0;
+    H.nodes.clear(); H.ranges.clear(); H.pos.clear(); H.dircol.clear(); H.n_node = 0; H.n_photon = 0;
     if (d->n_node <= 0 || d->n_photon <= 0) return true;
     if (!d->photons || !d->node_bbox || !d->node_child || !d->node_off) { err = "photons: null tables"; return false; }
-    const int nref = d->node_off[d->n_node];
+    const int N = d->n_node;
+    const int nref = d->node_off[N];
     if (d->node_off[0] != 0 || nref < 0 || (nref && !d->node_idx)) { err = "photons: bad leaf table"; return false; }
     for (int r = 0; r < nref; r++)
         if (d->node_idx[r] < 0 || d->node_idx[r] >= d->n_photon) { err = "photons: leaf reference out of range"; return false; }
-    std::vector<int32_t> skip((size_t)d->n_node, 0);
-    for (int n = d->n_node - 1; n >= 0; n--) {   // sub-tree end = max over children, children come later in pre-order
+    std::vector<int32_t> skip((size_t)N, 0);
+    for (int n = N - 1; n >= 0; n--) {   // sub-tree end = max over children, children come later in pre-order
         int32_t end = n + 1;
         for (int k = 0; k < 8; k++) {
             int ch = d->node_child[(size_t)n * 8 + k];
             if (ch == -1) continue;
-            if (ch <= n || ch >= d->n_node) { err = "photons: child index is not a later pre-order node"; return false; }
+            if (ch <= n || ch >= N) { err = "photons: child index is not a later pre-order node"; return false; }
             end = std::max(end, skip[ch]);
         }
         skip[n] = end;
     }
-    for (int n = 0; n < d->n_node; n++) {
+    for (int n = 0; n < N; n++) {
         int32_t expect = n + 1;
         const bool leaf = d->node_child[(size_t)n * 8] == -1;
+        if (d->node_off[n + 1] < d->node_off[n]) { err = "photons: leaf offsets not monotone"; return false; }
         for (int k = 0; k < 8; k++) {
             int ch = d->node_child[(size_t)n * 8 + k];
             if (leaf) { if (ch != -1) { err = "photons: node with partial children"; return false; } continue; }
@@ -226,16 +234,7 @@ inline bool layout_photons(const gi_photon_map_desc* d, HostPhotons& H, std::str
             expect = skip[ch];
         }
     }
-    H.nodes.resize((size_t)d->n_node);
-    for (int n = 0; n < d->n_node; n++) {
-        PNode& t = H.nodes[n];
-        for (int k = 0; k < 3; k++) { t.bmin[k] = d->node_bbox[(size_t)n * 6 + k]; t.bmax[k] = d->node_bbox[(size_t)n * 6 + 3 + k]; }
-        t.skip = skip[n];
-        t.first = d->node_off[n];
-        t.count = d->node_off[n + 1] - d->node_off[n];
-        t.is_leaf = d->node_child[(size_t)n * 8] == -1 ? 1 : 0;
-        if (t.count < 0) { err = "photons: leaf offsets not monotone"; return false; }
-    }
+    // (1) photons in leaf (DFS) order
     H.pos.resize((size_t)nref * 3);
     H.dircol.resize((size_t)nref * 6);
     for (int r = 0; r < nref; r++) {
@@ -243,7 +242,64 @@ inline bool layout_photons(const gi_photon_map_desc* d, HostPhotons& H, std::str
         for (int k = 0; k < 3; k++) H.pos[(size_t)r * 3 + k] = p[k];
         for (int k = 0; k < 6; k++) H.dircol[(size_t)r * 6 + k] = p[3 + k];
     }
-    H.n_node = d->n_node; H.n_photon = nref;
+    // (2) records with consecutive children: breadth-first numbering
+    std::vector<int32_t> rec_of((size_t)N, -1), order;
+    order.reserve((size_t)N);
+    rec_of[0] = 0;
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); head++) {
+        const int n = order[head];
+        if (d->node_child[(size_t)n * 8] == -1) continue;
+        for (int k = 0; k < 8; k++) {
+            const int ch = d->node_child[(size_t)n * 8 + k];
+            rec_of[ch] = (int32_t)order.size();
+            order.push_back(ch);
+        }
+    }
+    if ((int)order.size() != N) { err = "photons: tree is not connected"; return false; }
+    H.nodes.assign((size_t)N, PNode());
+    auto box_of = [&](int n, double* lo, double* hi) { for (int k = 0; k < 3; k++) { lo[k] = d->node_bbox[(size_t)n * 6 + k]; hi[k] = d->node_bbox[(size_t)n * 6 + 3 + k]; } };
+    // (3) candidate ranges per leaf: the reference's get() on the canonical tree, sub-trees skipped with the pre-order links
+    for (int n = 0; n < N; n++) {
+        PNode& t = H.nodes[(size_t)rec_of[n]];
+        memset(&t, 0, sizeof t);
+        box_of(n, t.bmin, t.bmax);
+        const bool leaf = d->node_child[(size_t)n * 8] == -1;
+        t.first_child = leaf ? -1 : rec_of[d->node_child[(size_t)n * 8]];
+        if (!leaf) {
+            const int c7 = d->node_child[(size_t)n * 8 + 7];
+            for (int k = 0; k < 3; k++) t.mid[k] = d->node_bbox[(size_t)c7 * 6 + k];
+            continue;
+        }
+        double qlo[3], qhi[3];
+        for (int k = 0; k < 3; k++) { qlo[k] = t.bmin[k] - GI_EPSILON; qhi[k] = t.bmax[k] + GI_EPSILON; }
+        t.nb_off = (int32_t)H.ranges.size();
+        int total = 0;
+        if (!(qhi[0] - qlo[0] <= 0)) {   // include/photonMap.cpp:73-74
+            int m = 0;
+            while (m < N) {
+                bool take = true;
+                if (m != 0) {   // the root itself is not tested (PhotonMap::getInRange calls _root.get directly)
+                    double lo[3], hi[3];
+                    box_of(m, lo, hi);
+                    take = (lo[0] <= qhi[0] && hi[0] >= qlo[0]) && (lo[1] <= qhi[1] && hi[1] >= qlo[1]) && (lo[2] <= qhi[2] && hi[2] >= qlo[2]);   // include/bbox.h:33-38
+                }
+                if (!take) { m = skip[m]; continue; }
+                if (d->node_child[(size_t)m * 8] != -1) { m = m + 1; continue; }
+                const int first = d->node_off[m], count = d->node_off[m + 1] - d->node_off[m];
+                if (count > 0) {
+                    if ((int32_t)H.ranges.size() > t.nb_off && H.ranges.back().first + H.ranges.back().count == first) H.ranges.back().count += count;
+                    else { PRange rg; rg.first = first; rg.count = count; H.ranges.push_back(rg); }
+                    total += count;
+                }
+                m = skip[m];
+            }
+        }
+        t.nb_cnt = (int32_t)H.ranges.size() - t.nb_off;
+        t.nb_photons = total;
+    }
+    if (H.ranges.empty()) { PRange z; z.first = 0; z.count = 0; H.ranges.push_back(z); }
+    H.n_node = N; H.n_photon = nref;
     return true;
 }
 

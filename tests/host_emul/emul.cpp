@@ -23,7 +23,7 @@ struct Emul {
         S.mats = hs.mats.data(); S.lights = hs.lights.data();
         S.n_node = hs.n_node; S.n_tri = hs.n_tri; S.n_light = hs.n_light;
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];
-        S.pnodes = hp.nodes.data(); S.ph_pos = hp.pos.data(); S.ph_dircol = hp.dircol.data();
+        S.pnodes = hp.nodes.data(); S.pranges = hp.ranges.data(); S.ph_pos = hp.pos.data(); S.ph_dircol = hp.dircol.data();
         S.n_pnode = hp.n_node; S.n_photon = hp.n_photon;
         S.hdims = hdims.data(); S.htable = htable.data();
     }
