@@ -308,85 +308,43 @@ GI_HD bool tri_hit(const TriGeom& g, const Ray& ray, double& u, double& v, doubl
 
 struct HitRec { V3 pos; double u, v; int32_t tri; };
 
-// RayTracer::trace as a resumable state machine: one step = one node (box test) or one triangle (intersection test).
-// Leaves are met in the order the reference's t0-sorted list has them because each of the 8 node arrays is laid out
-// front-to-back for its direction octant; the walk stops after the first leaf that contains a new nearest hit.
-// A plain per-lane loop over trace_step() gives trace(); the persistent kernels interleave the steps of 64 rays per wave and
-// hand a lane its next ray as soon as its current one is finished.
-struct TraceState {
-    Ray ray;
-    const TNode* tree;
-    Rng rng;
-    uint32_t alpha_purpose;
-    int32_t node, after_leaf, leaf_node, first, cnt, k;
-    bool in_leaf, term, intersected;
-    double best_d2;
-    HitRec best;
-};
-GI_HD void trace_begin(const Scene& S, TraceState& t, const Ray& ray, const Rng& rng, uint32_t alpha_purpose)
-{
-    t.ray = ray;
-    t.tree = S.tnodes + (size_t)dir_octant(ray) * (size_t)S.n_node;
-    t.rng = rng; t.alpha_purpose = alpha_purpose;
-    t.node = 0; t.after_leaf = 0; t.leaf_node = 0; t.first = 0; t.cnt = 0; t.k = 0;
-    t.in_leaf = false; t.term = false; t.intersected = false;
-    t.best_d2 = 0;
-    t.best.tri = -1; t.best.pos = v3(0, 0, 0); t.best.u = 0; t.best.v = 0;
-}
-// returns true when the ray is finished (t.intersected / t.best hold the result)
-GI_HD bool trace_step(const Scene& S, TraceState& t, Counters* c)
-{
-    if (t.in_leaf) {
-        const int32_t ti = S.leaf_refs[t.first + t.k];
-        t.k++;
-        const TriGeom& g = S.tris[ti];
-        double u, v, tt;
-        if (c) c->tri++;
-        if (tri_hit(g, t.ray, u, v, tt)) {
-            bool accept = true;
-            if (!(g.flags & 2u)) {
-                const Mat& m = S.mats[g.mat];
-                accept = rng_draw(t.rng, t.alpha_purpose, (uint32_t)t.tree[t.leaf_node].leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1;
-            }
-            if (accept) {
-                V3 hp = t.ray.o + tt * t.ray.d;
-                double d2 = len2(hp - t.ray.o);
-                if (!t.intersected || d2 < t.best_d2) {
-                    t.best.pos = hp; t.best.u = u; t.best.v = v; t.best.tri = ti;
-                    t.best_d2 = d2;
-                    t.intersected = true;
-                    const TNode& lf = t.tree[t.leaf_node];
-                    if (box_contains(lf.bmin, lf.bmax, hp)) t.term = true;
-                }
-            }
-        }
-        if (t.k < t.cnt) return false;
-        t.in_leaf = false;
-        if (t.term) return true;
-        t.node = t.after_leaf;
-        return t.node >= S.n_node;
-    }
-    const TNode& nd = t.tree[t.node];
-    if (c) c->v_trace++;
-    if (!box_hit(nd.bmin, nd.bmax, t.ray, 0.0, INFINITY)) t.node = nd.skip;
-    else if (nd.n_ref < 0) t.node = t.node + 1;
-    else if (nd.n_ref == 0) t.node = nd.skip;
-    else {
-        t.in_leaf = true;
-        t.leaf_node = t.node; t.after_leaf = nd.skip;
-        t.first = nd.first_ref; t.cnt = nd.n_ref; t.k = 0;
-        return false;
-    }
-    return t.node >= S.n_node;
-}
+// RayTracer::trace.  Leaves are met in the order the reference's t0-sorted list has them because each of the 8 node arrays
+// is laid out front-to-back for its direction octant; the loop stops after the first leaf that contains a new nearest hit.
 GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
-    TraceState t;
-    trace_begin(S, t, ray, rng, alpha_purpose);
+    const TNode* tree = S.tnodes + (size_t)dir_octant(ray) * (size_t)S.n_node;
+    bool intersected = false, term = false;
+    double best_d2 = 0;
+    int32_t node = 0;
     if (c) c->traces++;
-    while (!trace_step(S, t, c)) {}
-    best = t.best;
-    return t.intersected;
+    while (node < S.n_node && !term) {
+        const TNode& nd = tree[node];
+        if (c) c->v_trace++;
+        if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, INFINITY)) { node = nd.skip; continue; }
+        if (nd.n_ref < 0) { node = node + 1; continue; }
+        const int32_t first = nd.first_ref, cnt = nd.n_ref;
+        for (int32_t k = 0; k < cnt; k++) {
+            const int32_t ti = S.leaf_refs[first + k];
+            const TriGeom& g = S.tris[ti];
+            double u, v, t;
+            if (c) c->tri++;
+            if (!tri_hit(g, ray, u, v, t)) continue;
+            if (!(g.flags & 2u)) {
+                const Mat& m = S.mats[g.mat];
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)nd.leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+            }
+            V3 hp = ray.o + t * ray.d;
+            double d2 = len2(hp - ray.o);
+            if (!intersected || d2 < best_d2) {
+                best.pos = hp; best.u = u; best.v = v; best.tri = ti;
+                best_d2 = d2;
+                intersected = true;
+                if (box_contains(nd.bmin, nd.bmax, hp)) term = true;
+            }
+        }
+        node = nd.skip;
+    }
+    return intersected;
 }
 
 // RayTracer::visible: any accepted hit with 0 < |hit-o|^2 < mt among the entities of every leaf the segment touches.
@@ -637,30 +595,20 @@ GI_HD void path_begin(PathRec& p, const Ray& ray, uint32_t sample)
     p.stream = sample; p.depth = 0; p.htri = -1; p.pad = 0;
 }
 // stage 1: RayTracer::trace for the current segment.  Miss: L += T*ambient and the path is finished (returns false).
-GI_HD void stage_trace_begin(const Scene& S, const PathRec& p, uint64_t seed, TraceState& t)
+GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     Rng rng = rng_make(seed, p.stream);
     rng.depth = (uint32_t)p.depth;
-    trace_begin(S, t, make_ray_exact(ld3(p.o), ld3(p.d)), rng, P_TRACE_ALPHA);
-}
-GI_HD bool stage_trace_end(const Scene& S, PathRec& p, const TraceState& t)
-{
-    if (!t.intersected) {
+    Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
+    HitRec h;
+    if (!trace(S, ray, rng, P_TRACE_ALPHA, h, c)) {
         V3 L = ld3(p.L) + ld3(p.T) * ld3(S.ambient);
         p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
         return false;
     }
-    p.hpos[0] = t.best.pos.x; p.hpos[1] = t.best.pos.y; p.hpos[2] = t.best.pos.z;
-    p.hu = t.best.u; p.hv = t.best.v; p.htri = t.best.tri;
+    p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
+    p.hu = h.u; p.hv = h.v; p.htri = h.tri;
     return true;
-}
-GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
-{
-    TraceState t;
-    stage_trace_begin(S, p, seed, t);
-    if (c) c->traces++;
-    while (!trace_step(S, t, c)) {}
-    return stage_trace_end(S, p, t);
 }
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
 GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_wf_accum(Frame F, PixRec* pix, con
 // sample id = s * n_pix + i  (i = 8x8-tile-ordered pixel index): consecutive ids are neighbouring pixels of one sample index.
 struct StreamCtl {
     unsigned long long next_sample;   // next sample id to start
-    unsigned int n_new, n_cont, n_shade, n_gather, n_free, head;
+    unsigned int n_new, n_cont, n_shade, n_gather, n_free, pad;
 };
 
 __device__ __forceinline__ void st_finish(const PathRec& p, uint32_t slot, const unsigned long long* slot_sample, unsigned long long sample0,
@@ -280,63 +280,25 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec
     }
 }
 
-// Persistent trace pass: every lane walks its own ray one step (node or triangle) per iteration; a lane whose ray is finished
-// takes the next one from its wave's chunk of the input queue (chunks of GI_CHUNK rays are reserved with one atomic), so waves
-// stay full although rays need very different numbers of steps.
-#define GI_CHUNK 256
 __global__ __launch_bounds__(GI_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = n_a + n_b;
-    uint32_t chunk_next = 0, chunk_end = 0;   // wave-uniform
-    bool exhausted = false;                   // wave-uniform
-    bool have = false;
-    uint32_t slot = 0;
-    TraceState t;
-    for (;;) {
-        // ---- hand out rays to idle lanes
-        unsigned long long need = __ballot(!have);
-        while (need != 0ull && !exhausted) {
-            if (chunk_next == chunk_end) {
-                unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(&ctl->head, (unsigned int)GI_CHUNK);
-                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-                if (base >= n_in) { exhausted = true; break; }
-                chunk_next = base;
-                chunk_end = min(base + (uint32_t)GI_CHUNK, n_in);
-            }
-            const uint32_t avail = chunk_end - chunk_next;
-            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            const bool take = !have && rank < avail;
-            if (take) {
-                const uint32_t i = chunk_next + rank;
-                slot = i < n_a ? q_a[i] : q_b[i - n_a];
-                have = true;
-                t.node = -1;    // marks "just fetched"
-            }
-            chunk_next += min((uint32_t)__popcll(need), avail);
-            need = __ballot(!have);
-        }
-        if (__ballot(have) == 0ull) break;
-        // ---- one step per lane
-        bool done = false, hit = false;
-        if (have) {
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        bool hit = false, fin = false;
+        uint32_t slot = 0;
+        if (i < n_in) {
+            slot = i < n_a ? q_a[i] : q_b[i - n_a];
             PathRec& p = pool[slot];
-            if (t.node < 0) {
-                if (p.depth > GI_MAX_DEPTH) done = true;             // radiance() returns 0 past MAX_DEPTH: retire
-                else stage_trace_begin(S, p, seed, t);
-            }
-            if (!done && trace_step(S, t, nullptr)) {
-                hit = stage_trace_end(S, p, t);
-                done = true;
-            }
+            if (p.depth > GI_MAX_DEPTH) fin = true;            // radiance() returns 0 past MAX_DEPTH
+            else { hit = stage_trace(S, p, seed, nullptr); fin = !hit; }
         }
-        const uint32_t at = wave_append(&ctl->n_shade, done && hit);
-        if (done && hit) q_shade[at] = slot;
-        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free, &ctl->n_free, done && !hit);
-        if (done) have = false;
+        const uint32_t at = wave_append(&ctl->n_shade, hit);
+        if (hit) q_shade[at] = slot;
+        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free, &ctl->n_free, fin);
     }
 }
 
@@ -822,7 +784,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             if (n_new + n_cont == 0) break;
             // reset the per-pass counters (next_sample is preserved)
             StreamCtl hz = *c->h_ctl;
-            hz.n_new = 0; hz.n_cont = 0; hz.n_shade = 0; hz.n_gather = 0; hz.n_free = 0; hz.head = 0;
+            hz.n_new = 0; hz.n_cont = 0; hz.n_shade = 0; hz.n_gather = 0; hz.n_free = 0;
             *c->h_ctl = hz;
             HIP_TRY(c, hipMemcpyAsync(ctl, c->h_ctl, sizeof(StreamCtl), hipMemcpyHostToDevice, st));
             uint32_t* qfree_out = q_free[ping];
