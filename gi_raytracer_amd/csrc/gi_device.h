@@ -424,25 +424,29 @@ GI_HD bool boxes_touch(const double* amin, const double* amax, const double* qmi
 //   pass 1: 32nd smallest float key tau (heap);   pass 2: exact sums of everything with key < tau, and of the key == tau group;
 //   if the tie group is larger than what is still needed (float ties straddling rank 32: rare) pass 3 picks the needed ones by
 //   exact distance.
-GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
+// PhotonMap::Node::getBounds (include/photonMap.cpp:115-134): the leaf whose half-open box contains pos, or -1.  The children
+// are the 8 octants around `mid`, so the only child that can contain pos is the one on pos's side of mid on every axis
+// (x = bit0, z = bit1, y = bit2); its contains() test is still made, because the upper children end at mid + .5*extent, which
+// may fall an ulp short of the parent's box.
+GI_HD int32_t gather_find_leaf(const Scene& S, V3 pos)
 {
-    V3 res = v3(0, 0, 0);
-    if (n_cand_out) *n_cand_out = 0;
-    if (c) c->gathers++;
-    if (S.n_pnode <= 0) return res;
-    // PhotonMap::Node::getBounds (include/photonMap.cpp:115-134): descend to the leaf whose half-open box contains pos.  The
-    // children are the 8 octants around `mid`, so the only child that can contain pos is the one on pos's side of mid on every
-    // axis (x = bit0, z = bit1, y = bit2); its contains() test is still made, because the upper children end at mid + .5*extent,
-    // which may fall an ulp short of the parent's box.
+    if (S.n_pnode <= 0) return -1;
     int32_t node = 0;
     while (S.pnodes[node].first_child >= 0) {
         const PNode& nd = S.pnodes[node];
         const int k = (pos.x >= nd.mid[0] ? 1 : 0) | (pos.z >= nd.mid[2] ? 2 : 0) | (pos.y >= nd.mid[1] ? 4 : 0);
         const int32_t ch = nd.first_child + k;
         const PNode& cn = S.pnodes[ch];
-        if (!box_contains(cn.bmin, cn.bmax, pos)) return res;   // no child contains pos: box of -inf, nothing is collected
+        if (!box_contains(cn.bmin, cn.bmax, pos)) return -1;   // no child contains pos: box of -inf, nothing is collected
         node = ch;
     }
+    return node;
+}
+GI_HD V3 gather_in_leaf(const Scene& S, int32_t node, V3 pos, V3 dir, float* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
+{
+    V3 res = v3(0, 0, 0);
+    if (n_cand_out) *n_cand_out = 0;
+    if (node < 0) return res;
     // PhotonMap::Node::get (include/photonMap.cpp:71-92) for this leaf's (+-EPSILON) box was run once per leaf when the map was
     // laid out (gi_layout.h): its result is the list of photon ranges [nb_off, nb_off + nb_cnt)
     const PNode& lf = S.pnodes[node];
@@ -514,6 +518,11 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride
     }
     res = res / (GI_PI * r2);
     return res;
+}
+GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
+{
+    if (c) c->gathers++;
+    return gather_in_leaf(S, gather_find_leaf(S, pos), pos, dir, heap_mem, heap_stride, n_cand_out, c);
 }
 
 // ------------------------------------------------------------------------------------------------ shading
@@ -673,6 +682,12 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     return 0;
 }
 // stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
+GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride)
+{
+    V3 caustic = gather_in_leaf(S, leaf, ld3(p.hpos), ld3(p.gdir), heap_mem, heap_stride, nullptr, nullptr);
+    V3 L = ld3(p.L) + ld3(p.gcoef) * caustic;
+    p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+}
 GI_HD void stage_gather(const Scene& S, PathRec& p, float* heap_mem, int heap_stride, Counters* c)
 {
     V3 caustic = gather(S, ld3(p.hpos), ld3(p.gdir), heap_mem, heap_stride, nullptr, c);

@@ -7,6 +7,7 @@
 // Host side of this file: device layouts (8 direction-ordered copies of the octree, leaf-ordered photons, Halton tables)
 // and the gi_* entry points.  No CPU fallback exists: every entry needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -326,12 +327,26 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_shade(Scene S, uint64_t seed, P
     }
 }
 
-__global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, const uint32_t* q_gather, const StreamCtl* ctl)
+// gather queries are sorted by the photon-map leaf that contains them: queries of one leaf share their candidate photons, so
+// the lanes of a wave read the same photons (one cache line instead of 64) and run loops of equal length
+__global__ __launch_bounds__(GI_BLOCK) void k_st_gkeys(Scene S, const PathRec* pool, const uint32_t* q_gather, const StreamCtl* ctl, uint32_t* keys, uint32_t* vals)
+{
+    const uint32_t n_in = ctl->n_gather;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = q_gather[i];
+        const int32_t leaf = gather_find_leaf(S, ld3(pool[slot].hpos));
+        keys[i] = leaf < 0 ? (uint32_t)S.n_pnode : (uint32_t)leaf;
+        vals[i] = slot;
+    }
+}
+__global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in)
 {
     __shared__ float heap[GI_GATHER_K * GI_BLOCK];
-    const uint32_t n_in = ctl->n_gather;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x)
-        stage_gather(S, pool[q_gather[i]], heap + threadIdx.x, GI_BLOCK, nullptr);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
+        const uint32_t leaf = keys[i];
+        if (leaf >= (uint32_t)S.n_pnode) continue;   // no leaf contains the point: the caustic term is 0
+        stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap + threadIdx.x, GI_BLOCK);
+    }
 }
 
 // fold samples [s0, s0 + ns) of every pixel into its running mean, in sample order (include/raytracer.h:131-147)
@@ -502,6 +517,8 @@ struct gi_ctx {
     DevBuf<unsigned long long> d_slot_sample;
     DevBuf<uint32_t> d_qs[6];         // streaming queues: new, cont ping, cont pong, shade, gather, free ping/pong share [5] + d_q
     DevBuf<StreamCtl> d_ctl;
+    DevBuf<uint32_t> d_gk[2], d_gv[2];   // gather sort: keys / values, in / out
+    DevBuf<unsigned char> d_sort_tmp;
     StreamCtl* h_ctl = nullptr;
     size_t lbuf_bytes_max = (size_t)16 << 30;
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
@@ -737,6 +754,12 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     for (int k = 0; k < 6; k++) if (c->d_qs[k].n < P) HIP_TRY(c, c->d_qs[k].alloc(P));
     if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
     if (c->d_lbuf.n < (size_t)n_pix * chunk * 3) HIP_TRY(c, c->d_lbuf.alloc((size_t)n_pix * chunk * 3));
+    for (int k = 0; k < 2; k++) { if (c->d_gk[k].n < P) HIP_TRY(c, c->d_gk[k].alloc(P)); if (c->d_gv[k].n < P) HIP_TRY(c, c->d_gv[k].alloc(P)); }
+    {
+        size_t need = 0;
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0, 32, c->stream));
+        if (c->d_sort_tmp.n < need) HIP_TRY(c, c->d_sort_tmp.alloc(need));
+    }
     if (!c->d_ctl.p) HIP_TRY(c, c->d_ctl.alloc(1));
     if (!c->h_ctl) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, sizeof(StreamCtl), hipHostMallocDefault));
     static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0;
@@ -795,9 +818,18 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, qcont_out, q_gather,
                                qfree_out, c->d_lbuf.p);
             launches += 2;
-            if (c->S.n_pnode > 0) { hipLaunchKernelGGL(k_st_gather, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl); launches++; }
             HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
+            const uint32_t n_gather = c->h_ctl->n_gather;
+            if (c->S.n_pnode > 0 && n_gather > 0) {
+                int bits = 1;
+                while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
+                hipLaunchKernelGGL(k_st_gkeys, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p);
+                size_t tmp_bytes = c->d_sort_tmp.n;
+                HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
+                hipLaunchKernelGGL(k_st_gather, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather);
+                launches += 3;
+            }
             n_cont = c->h_ctl->n_cont;
             n_free = c->h_ctl->n_free;
             qf = qfree_out;
