@@ -310,19 +310,32 @@ struct HitRec { V3 pos; double u, v; int32_t tri; };
 
 // RayTracer::trace.  Leaves are met in the order the reference's t0-sorted list has them because each of the 8 node arrays
 // is laid out front-to-back for its direction octant; the loop stops after the first leaf that contains a new nearest hit.
+// Control flow is "while-while": an inner loop walks nodes until THIS lane stands on a non-empty leaf, then the leaf's
+// triangles are tested; the 64 lanes of a wave therefore do their node steps together and their triangle tests together instead
+// of one lane's triangle loop stalling 63 lanes that want to take a node step.
 GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
     const TNode* tree = S.tnodes + (size_t)dir_octant(ray) * (size_t)S.n_node;
-    bool intersected = false, term = false;
+    bool intersected = false;
     double best_d2 = 0;
     int32_t node = 0;
     if (c) c->traces++;
-    while (node < S.n_node && !term) {
-        const TNode& nd = tree[node];
-        if (c) c->v_trace++;
-        if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, INFINITY)) { node = nd.skip; continue; }
-        if (nd.n_ref < 0) { node = node + 1; continue; }
-        const int32_t first = nd.first_ref, cnt = nd.n_ref;
+    for (;;) {
+        // ---- next non-empty leaf the ray touches
+        int32_t first = 0, cnt = 0, leaf = -1;
+        while (node < S.n_node) {
+            const TNode& nd = tree[node];
+            if (c) c->v_trace++;
+            if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, INFINITY)) { node = nd.skip; continue; }
+            if (nd.n_ref < 0) { node = node + 1; continue; }
+            if (nd.n_ref == 0) { node = nd.skip; continue; }
+            leaf = node; first = nd.first_ref; cnt = nd.n_ref;
+            node = nd.skip;
+            break;
+        }
+        if (leaf < 0) break;
+        // ---- its triangles
+        bool term = false;
         for (int32_t k = 0; k < cnt; k++) {
             const int32_t ti = S.leaf_refs[first + k];
             const TriGeom& g = S.tris[ti];
@@ -331,7 +344,7 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
             if (!tri_hit(g, ray, u, v, t)) continue;
             if (!(g.flags & 2u)) {
                 const Mat& m = S.mats[g.mat];
-                if (!(rng_draw(rng, alpha_purpose, (uint32_t)nd.leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)tree[leaf].leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
             }
             V3 hp = ray.o + t * ray.d;
             double d2 = len2(hp - ray.o);
@@ -339,10 +352,11 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
                 best.pos = hp; best.u = u; best.v = v; best.tri = ti;
                 best_d2 = d2;
                 intersected = true;
-                if (box_contains(nd.bmin, nd.bmax, hp)) term = true;
+                const TNode& lf = tree[leaf];
+                if (box_contains(lf.bmin, lf.bmax, hp)) term = true;
             }
         }
-        node = nd.skip;
+        if (term) break;
     }
     return intersected;
 }
@@ -354,12 +368,19 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
     const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
     int32_t node = 0;
     if (c) c->shadows++;
-    while (node < S.n_node) {
-        const TNode& nd = tree[node];
-        if (c) c->v_shadow++;
-        if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, tmax)) { node = nd.skip; continue; }
-        if (nd.n_ref < 0) { node = node + 1; continue; }
-        const int32_t first = nd.first_ref, cnt = nd.n_ref;
+    for (;;) {
+        int32_t first = 0, cnt = 0, leaf = -1;
+        while (node < S.n_node) {
+            const TNode& nd = tree[node];
+            if (c) c->v_shadow++;
+            if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, tmax)) { node = nd.skip; continue; }
+            if (nd.n_ref < 0) { node = node + 1; continue; }
+            if (nd.n_ref == 0) { node = nd.skip; continue; }
+            leaf = node; first = nd.first_ref; cnt = nd.n_ref;
+            node = nd.skip;
+            break;
+        }
+        if (leaf < 0) break;
         for (int32_t k = 0; k < cnt; k++) {
             const int32_t ti = S.leaf_refs[first + k];
             const TriGeom& g = S.tris[ti];
@@ -368,13 +389,12 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
             if (!tri_hit(g, ray, u, v, t)) continue;
             if (!(g.flags & 2u)) {
                 const Mat& m = S.mats[g.mat];
-                if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)nd.leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)tree[leaf].leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
             }
             V3 hp = ray.o + t * ray.d;
             double ts = len2(hp - ray.o);
             if ((ts < mt) && (ts > 0)) return false;
         }
-        node = nd.skip;
     }
     return true;
 }
