@@ -303,8 +303,27 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_trace(Scene S, uint64_t seed, P
     }
 }
 
+// coherence key of a continuing ray: direction octant (selects the node array), Morton code of the origin inside the root box,
+// coarse direction -- rays that are neighbours in this order walk the same nodes for about the same number of steps
+__device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& p)
+{
+    const TNode& root = S.tnodes[0];
+    uint32_t m = 0;
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+        double f = (p.o[k] - root.bmin[k]) / (root.bmax[k] - root.bmin[k]);
+        f = f < 0.0 ? 0.0 : (f > 0.999 ? 0.999 : f);
+        q[k] = (uint32_t)(f * 64.0);
+    }
+    for (int b = 5; b >= 0; b--) m = (m << 3) | (((q[0] >> b) & 1u) << 2) | (((q[1] >> b) & 1u) << 1) | ((q[2] >> b) & 1u);
+    const uint32_t oct = (p.d[0] < 0.0 ? 1u : 0u) | (p.d[2] < 0.0 ? 2u : 0u) | (p.d[1] < 0.0 ? 4u : 0u);
+    uint32_t db = 0;
+    for (int k = 0; k < 3; k++) { double a = fabs(p.d[k]); db = (db << 2) | (uint32_t)(a >= 0.999 ? 3.0 : a * 4.0); }
+    return (oct << 24) | (m << 6) | db;
+}
+
 __global__ __launch_bounds__(GI_BLOCK) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
-                                                       const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
+                                                       const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
 {
     const uint32_t n_in = ctl->n_shade;
     const uint32_t lane = threadIdx.x & 63u;
@@ -320,7 +339,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_shade(Scene S, uint64_t seed, P
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
         const uint32_t a = wave_append(&ctl->n_cont, cont);
-        if (cont) q_cont[a] = slot;
+        if (cont) { q_cont[a] = slot; k_cont[a] = ray_sort_key(S, pool[slot]); }
         const uint32_t g = wave_append(&ctl->n_gather, (fl & ST_GATHER) != 0);
         if (fl & ST_GATHER) q_gather[g] = slot;
         st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free, &ctl->n_free, valid && !cont);
@@ -518,6 +537,7 @@ struct gi_ctx {
     DevBuf<uint32_t> d_qs[6];         // streaming queues: new, cont ping, cont pong, shade, gather, free ping/pong share [5] + d_q
     DevBuf<StreamCtl> d_ctl;
     DevBuf<uint32_t> d_gk[2], d_gv[2];   // gather sort: keys / values, in / out
+    DevBuf<uint32_t> d_ck[2], d_cv;      // continuing-ray sort: keys in / out, unsorted slots
     DevBuf<unsigned char> d_sort_tmp;
     StreamCtl* h_ctl = nullptr;
     size_t lbuf_bytes_max = (size_t)16 << 30;
@@ -755,6 +775,8 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
     if (c->d_lbuf.n < (size_t)n_pix * chunk * 3) HIP_TRY(c, c->d_lbuf.alloc((size_t)n_pix * chunk * 3));
     for (int k = 0; k < 2; k++) { if (c->d_gk[k].n < P) HIP_TRY(c, c->d_gk[k].alloc(P)); if (c->d_gv[k].n < P) HIP_TRY(c, c->d_gv[k].alloc(P)); }
+    for (int k = 0; k < 2; k++) if (c->d_ck[k].n < P) HIP_TRY(c, c->d_ck[k].alloc(P));
+    if (c->d_cv.n < P) HIP_TRY(c, c->d_cv.alloc(P));
     {
         size_t need = 0;
         HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0, 32, c->stream));
@@ -815,7 +837,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             const uint32_t* qcont_in = q_cont[ping ^ 1];
             hipLaunchKernelGGL(k_st_trace, dim3(g_trace), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
                                q_shade, qfree_out, c->d_lbuf.p);
-            hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, qcont_out, q_gather,
+            hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
                                qfree_out, c->d_lbuf.p);
             launches += 2;
             HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
@@ -832,6 +854,11 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             }
             n_cont = c->h_ctl->n_cont;
             n_free = c->h_ctl->n_free;
+            if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
+                size_t tmp_bytes = c->d_sort_tmp.n;
+                HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, 0, 27, st));
+                launches++;
+            }
             qf = qfree_out;
             ping ^= 1;
             if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u next %llu/%llu\n", n_new, n_cont, n_free, c->h_ctl->n_gather, c->h_ctl->next_sample, sample_end);
