@@ -24,6 +24,9 @@
 #ifndef GI_HD
 #define GI_HD __host__ __device__ __forceinline__
 #endif
+#ifndef GI_HDM   // member functions
+#define GI_HDM __host__ __device__ __forceinline__
+#endif
 
 namespace gi {
 
@@ -36,12 +39,16 @@ namespace gi {
 #define GI_GATHER_K 32
 
 // ------------------------------------------------------------------------------------------------ device tables (HBM layout)
-struct TNode {              // 64 B: one node of one of the 8 direction-ordered pre-order copies of the scene octree
+struct NodeLink { int32_t hit, skip; };
+struct alignas(128) TNode { // 128 B = one L2 line: a scene-octree node, stored once, nodes in breadth-first order (top levels first,
+                            // so that a prefix of the array is what a kernel stages in LDS)
     double bmin[3], bmax[3];
-    int32_t skip;           // next node when this sub-tree is skipped (END = n_node)
     int32_t first_ref;      // leaves: first entry in leaf_refs
     int32_t n_ref;          // leaves: number of entries; inner nodes: -1
     int32_t leaf_id;        // canonical pre-order index (RNG key, same numbering as the CPU side)
+    int32_t pad;
+    NodeLink link[8];       // per direction octant: next node when the box is hit (inner nodes) / when the sub-tree is left;
+                            // following them visits the children of every node front to back for that octant; END = n_node
 };
 struct TriGeom {            // 80 B: what a ray-triangle test needs
     double p0[3], e1[3], e2[3];
@@ -63,7 +70,7 @@ struct PRange { int32_t first, count; };   // photons are stored leaf by leaf in
 struct HaltonDim { uint32_t P, n, off; float scale; };
 
 struct Scene {
-    const TNode* tnodes;      // [8][n_node]
+    const TNode* tnodes;      // [n_node]
     const int32_t* leaf_refs;
     const TriGeom* tris;
     const TriShade* shade;
@@ -308,14 +315,30 @@ GI_HD bool tri_hit(const TriGeom& g, const Ray& ray, double& u, double& v, doubl
 
 struct HitRec { V3 pos; double u, v; int32_t tri; };
 
-// RayTracer::trace.  Leaves are met in the order the reference's t0-sorted list has them because each of the 8 node arrays
-// is laid out front-to-back for its direction octant; the loop stops after the first leaf that contains a new nearest hit.
-// Control flow is "while-while": an inner loop walks nodes until THIS lane stands on a non-empty leaf, then the leaf's
-// triangles are tested; the 64 lanes of a wave therefore do their node steps together and their triangle tests together instead
-// of one lane's triangle loop stalling 63 lanes that want to take a node step.
-GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
+// Where node records come from: plain global memory here; gi_kernels.hip adds a source that serves the first nodes from LDS.
+struct NodeView { double bmin[3], bmax[3]; int32_t first_ref, n_ref, hit, skip; };
+struct GlobalNodes {
+    const TNode* g;
+    GI_HDM void fetch(int32_t i, int oct, NodeView& v) const
+    {
+        const TNode& n = g[i];
+        v.bmin[0] = n.bmin[0]; v.bmin[1] = n.bmin[1]; v.bmin[2] = n.bmin[2];
+        v.bmax[0] = n.bmax[0]; v.bmax[1] = n.bmax[1]; v.bmax[2] = n.bmax[2];
+        v.first_ref = n.first_ref; v.n_ref = n.n_ref;
+        v.hit = n.link[oct].hit; v.skip = n.link[oct].skip;
+    }
+    GI_HDM int32_t leaf_id(int32_t i) const { return g[i].leaf_id; }
+};
+
+// RayTracer::trace.  Leaves are met in the order the reference's t0-sorted list has them because the hit/skip links of a
+// direction octant visit the children of every node front to back; the walk stops after the first leaf that contains a new
+// nearest hit.  Control flow is "while-while": an inner loop walks nodes until THIS lane stands on a non-empty leaf, then the
+// leaf's triangles are tested; the 64 lanes of a wave therefore do their node steps together and their triangle tests together
+// instead of one lane's triangle loop stalling 63 lanes that want to take a node step.
+template <class Nodes>
+GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
-    const TNode* tree = S.tnodes + (size_t)dir_octant(ray) * (size_t)S.n_node;
+    const int oct = dir_octant(ray);
     bool intersected = false;
     double best_d2 = 0;
     int32_t node = 0;
@@ -323,13 +346,17 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
     for (;;) {
         // ---- next non-empty leaf the ray touches
         int32_t first = 0, cnt = 0, leaf = -1;
+        double lmin[3], lmax[3];
         while (node < S.n_node) {
-            const TNode& nd = tree[node];
+            NodeView nd;
+            N.fetch(node, oct, nd);
             if (c) c->v_trace++;
             if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, INFINITY)) { node = nd.skip; continue; }
-            if (nd.n_ref < 0) { node = node + 1; continue; }
+            if (nd.n_ref < 0) { node = nd.hit; continue; }
             if (nd.n_ref == 0) { node = nd.skip; continue; }
             leaf = node; first = nd.first_ref; cnt = nd.n_ref;
+            lmin[0] = nd.bmin[0]; lmin[1] = nd.bmin[1]; lmin[2] = nd.bmin[2];
+            lmax[0] = nd.bmax[0]; lmax[1] = nd.bmax[1]; lmax[2] = nd.bmax[2];
             node = nd.skip;
             break;
         }
@@ -344,7 +371,7 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
             if (!tri_hit(g, ray, u, v, t)) continue;
             if (!(g.flags & 2u)) {
                 const Mat& m = S.mats[g.mat];
-                if (!(rng_draw(rng, alpha_purpose, (uint32_t)tree[leaf].leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
             }
             V3 hp = ray.o + t * ray.d;
             double d2 = len2(hp - ray.o);
@@ -352,29 +379,36 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
                 best.pos = hp; best.u = u; best.v = v; best.tri = ti;
                 best_d2 = d2;
                 intersected = true;
-                const TNode& lf = tree[leaf];
-                if (box_contains(lf.bmin, lf.bmax, hp)) term = true;
+                if (box_contains(lmin, lmax, hp)) term = true;
             }
         }
         if (term) break;
     }
     return intersected;
 }
+GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
+{
+    GlobalNodes N;
+    N.g = S.tnodes;
+    return trace_nodes(S, N, ray, rng, alpha_purpose, best, c);
+}
 
 // RayTracer::visible: any accepted hit with 0 < |hit-o|^2 < mt among the entities of every leaf the segment touches.
-GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
+template <class Nodes>
+GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
-    const TNode* tree = S.tnodes + (size_t)dir_octant(ray) * (size_t)S.n_node;
+    const int oct = dir_octant(ray);
     const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
     int32_t node = 0;
     if (c) c->shadows++;
     for (;;) {
         int32_t first = 0, cnt = 0, leaf = -1;
         while (node < S.n_node) {
-            const TNode& nd = tree[node];
+            NodeView nd;
+            N.fetch(node, oct, nd);
             if (c) c->v_shadow++;
             if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, tmax)) { node = nd.skip; continue; }
-            if (nd.n_ref < 0) { node = node + 1; continue; }
+            if (nd.n_ref < 0) { node = nd.hit; continue; }
             if (nd.n_ref == 0) { node = nd.skip; continue; }
             leaf = node; first = nd.first_ref; cnt = nd.n_ref;
             node = nd.skip;
@@ -389,7 +423,7 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
             if (!tri_hit(g, ray, u, v, t)) continue;
             if (!(g.flags & 2u)) {
                 const Mat& m = S.mats[g.mat];
-                if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)tree[leaf].leaf_id, (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
             }
             V3 hp = ray.o + t * ray.d;
             double ts = len2(hp - ray.o);
@@ -397,6 +431,12 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
         }
     }
     return true;
+}
+GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
+{
+    GlobalNodes N;
+    N.g = S.tnodes;
+    return visible_nodes(S, N, ray, mt, rng, light_index, c);
 }
 
 // ------------------------------------------------------------------------------------------------ photon gather
@@ -624,13 +664,14 @@ GI_HD void path_begin(PathRec& p, const Ray& ray, uint32_t sample)
     p.stream = sample; p.depth = 0; p.htri = -1; p.pad = 0;
 }
 // stage 1: RayTracer::trace for the current segment.  Miss: L += T*ambient and the path is finished (returns false).
-GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
+template <class Nodes>
+GI_HD bool stage_trace_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c)
 {
     Rng rng = rng_make(seed, p.stream);
     rng.depth = (uint32_t)p.depth;
     Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
     HitRec h;
-    if (!trace(S, ray, rng, P_TRACE_ALPHA, h, c)) {
+    if (!trace_nodes(S, N, ray, rng, P_TRACE_ALPHA, h, c)) {
         V3 L = ld3(p.L) + ld3(p.T) * ld3(S.ambient);
         p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
         return false;
@@ -639,8 +680,15 @@ GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     p.hu = h.u; p.hv = h.v; p.htri = h.tri;
     return true;
 }
+GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
+{
+    GlobalNodes N;
+    N.g = S.tnodes;
+    return stage_trace_nodes(S, N, p, seed, c);
+}
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
-GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
+template <class Nodes>
+GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c)
 {
     Rng rng = rng_make(seed, p.stream);
     const int depth = p.depth;
@@ -667,7 +715,7 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
         double maxt = len2(lightDir);
         double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
         Ray sray = make_ray(so, lightDir);
-        if (visible(S, sray, maxt, rng, (uint32_t)li, c)) {
+        if (visible_nodes(S, N, sray, maxt, rng, (uint32_t)li, c)) {
             double d = dot(norm, normalize(lpos - h.pos));
             if (d < 0) d = 0;
             double l = pow(d, (1.0 / roughness));
@@ -700,6 +748,12 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     L = L + T * (color * i);
     p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
     return 0;
+}
+GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
+{
+    GlobalNodes N;
+    N.g = S.tnodes;
+    return stage_shade_nodes(S, N, p, seed, c);
 }
 // stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
 GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride)

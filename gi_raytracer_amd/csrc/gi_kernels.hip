@@ -71,6 +71,45 @@ __global__ __launch_bounds__(GI_BLOCK) void k_render(Scene S, Frame F, void* out
     }
 }
 
+// ================================================================================================= octree top in LDS
+// The traversal kernels of the streaming pipeline copy the first n_l node records (breadth-first order = the top levels of
+// the octree, which every ray visits) into LDS once per workgroup and read them from there; deeper nodes come from L1/L2.
+extern __shared__ __align__(128) unsigned char gi_dyn_lds[];
+#define GI_LDS_NODES 512                      // 64 KB of 128-byte records
+struct LdsNodes {
+    const TNode* g;
+    int32_t n_l;
+    __device__ __forceinline__ void fetch(int32_t i, int oct, NodeView& v) const
+    {
+        if (i < n_l) {
+            const TNode* l = reinterpret_cast<const TNode*>(gi_dyn_lds);
+            const TNode& n = l[i];
+            v.bmin[0] = n.bmin[0]; v.bmin[1] = n.bmin[1]; v.bmin[2] = n.bmin[2];
+            v.bmax[0] = n.bmax[0]; v.bmax[1] = n.bmax[1]; v.bmax[2] = n.bmax[2];
+            v.first_ref = n.first_ref; v.n_ref = n.n_ref;
+            v.hit = n.link[oct].hit; v.skip = n.link[oct].skip;
+        } else {
+            const TNode& n = g[i];
+            v.bmin[0] = n.bmin[0]; v.bmin[1] = n.bmin[1]; v.bmin[2] = n.bmin[2];
+            v.bmax[0] = n.bmax[0]; v.bmax[1] = n.bmax[1]; v.bmax[2] = n.bmax[2];
+            v.first_ref = n.first_ref; v.n_ref = n.n_ref;
+            v.hit = n.link[oct].hit; v.skip = n.link[oct].skip;
+        }
+    }
+    __device__ __forceinline__ int32_t leaf_id(int32_t i) const { return g[i].leaf_id; }
+};
+__device__ __forceinline__ LdsNodes stage_nodes_in_lds(const Scene& S)
+{
+    LdsNodes N;
+    N.g = S.tnodes;
+    N.n_l = S.n_node < GI_LDS_NODES ? S.n_node : GI_LDS_NODES;
+    const uint4* src = reinterpret_cast<const uint4*>(S.tnodes);
+    uint4* dst = reinterpret_cast<uint4*>(gi_dyn_lds);
+    for (int i = threadIdx.x; i < N.n_l * 8; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return N;
+}
+
 // ================================================================================================= wavefront pipeline
 // The frame is rendered in rounds.  In a round every pixel that still wants samples (adaptive loop of RayTracer::run,
 // include/raytracer.h:108-148) starts up to B paths (as many as it is certain to take whatever their variance turns out to
@@ -281,10 +320,13 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec
     }
 }
 
-__global__ __launch_bounds__(GI_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+#define GI_TRACE_BLOCK 1024
+#define GI_SHADE_BLOCK 512
+__global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf)
 {
+    const LdsNodes N = stage_nodes_in_lds(S);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = n_a + n_b;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
@@ -295,7 +337,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_trace(Scene S, uint64_t seed, P
             slot = i < n_a ? q_a[i] : q_b[i - n_a];
             PathRec& p = pool[slot];
             if (p.depth > GI_MAX_DEPTH) fin = true;            // radiance() returns 0 past MAX_DEPTH
-            else { hit = stage_trace(S, p, seed, nullptr); fin = !hit; }
+            else { hit = stage_trace_nodes(S, N, p, seed, nullptr); fin = !hit; }
         }
         const uint32_t at = wave_append(&ctl->n_shade, hit);
         if (hit) q_shade[at] = slot;
@@ -322,9 +364,10 @@ __device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& 
     return (oct << 24) | (m << 6) | db;
 }
 
-__global__ __launch_bounds__(GI_BLOCK) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+__global__ __launch_bounds__(GI_SHADE_BLOCK) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
 {
+    const LdsNodes N = stage_nodes_in_lds(S);
     const uint32_t n_in = ctl->n_shade;
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
@@ -334,7 +377,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_shade(Scene S, uint64_t seed, P
         uint32_t slot = 0;
         if (valid) {
             slot = q_shade[i];
-            fl = stage_shade(S, pool[slot], seed, nullptr);
+            fl = stage_shade_nodes(S, N, pool[slot], seed, nullptr);
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
@@ -662,10 +705,10 @@ int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
 
 int gi_local_rows(const gi_render_params* p) { return local_rows(p); }
 
-static int grid_for(gi_ctx* c, const void* kernel, size_t dyn_lds = 0)
+static int grid_for(gi_ctx* c, const void* kernel, size_t dyn_lds = 0, int block = GI_BLOCK)
 {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, GI_BLOCK, dyn_lds) != hipSuccess || per_cu <= 0) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dyn_lds) != hipSuccess || per_cu <= 0) per_cu = 1;
     return c->n_cu * per_cu;
 }
 
@@ -785,9 +828,10 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     if (!c->d_ctl.p) HIP_TRY(c, c->d_ctl.alloc(1));
     if (!c->h_ctl) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, sizeof(StreamCtl), hipHostMallocDefault));
     static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0;
+    const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
     if (!g_trace) {
-        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace);
-        g_shade = grid_for(c, (const void*)k_st_shade); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum);
+        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace, lds_nodes, GI_TRACE_BLOCK);
+        g_shade = grid_for(c, (const void*)k_st_shade, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum);
     }
     hipStream_t st = c->stream;
     PathRec* pool = c->d_pool.p;
@@ -835,9 +879,9 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             uint32_t* qfree_out = q_free[ping];
             uint32_t* qcont_out = q_cont[ping];
             const uint32_t* qcont_in = q_cont[ping ^ 1];
-            hipLaunchKernelGGL(k_st_trace, dim3(g_trace), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+            hipLaunchKernelGGL(k_st_trace, dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
                                q_shade, qfree_out, c->d_lbuf.p);
-            hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
+            hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
                                qfree_out, c->d_lbuf.p);
             launches += 2;
             HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));

@@ -125,39 +125,51 @@ inline bool validate_scene(const gi_scene_desc* d, std::string& err)
     return true;
 }
 
-// emit the direction-ordered pre-order copy `a` of the canonical tree (children visited as k ^ a: front to back for every
-// ray whose direction signs are `a`; child numbering x = bit0, z = bit1, y = bit2 as in include/octree.cpp:321-328)
-inline void emit_ordered(const gi_scene_desc* d, int a, int node, std::vector<TNode>& out)
+// per-octant links of the canonical tree: visiting the children of every node in the order k ^ a (k = 0..7) is front to back for
+// every ray whose direction signs are `a` (child numbering x = bit0, z = bit1, y = bit2 as in include/octree.cpp:321-328).
+// hit = first child in that order; skip = next sibling in that order, or the parent's skip after the last child.
+inline void link_octant(const gi_scene_desc* d, int a, int node, int32_t skip_to, const std::vector<int32_t>& rec_of, std::vector<TNode>& out)
 {
-    const size_t me = out.size();
-    TNode t;
-    for (int k = 0; k < 3; k++) { t.bmin[k] = d->node_bbox[(size_t)node * 6 + k]; t.bmax[k] = d->node_bbox[(size_t)node * 6 + 3 + k]; }
-    bool inner = false;
-    for (int k = 0; k < 8; k++) if (d->node_child[(size_t)node * 8 + k] >= 0) inner = true;
-    t.first_ref = d->node_ent_off[node];
-    t.n_ref = inner ? -1 : d->node_ent_off[node + 1] - d->node_ent_off[node];
-    t.leaf_id = node;
-    t.skip = 0;
-    out.push_back(t);
-    if (inner)
-        for (int k = 0; k < 8; k++) {
-            int ch = d->node_child[(size_t)node * 8 + (k ^ a)];
-            if (ch >= 0) emit_ordered(d, a, ch, out);
-        }
-    out[me].skip = (int32_t)out.size();
+    TNode& t = out[(size_t)rec_of[node]];
+    int kids[8], nk = 0;
+    for (int k = 0; k < 8; k++) { int ch = d->node_child[(size_t)node * 8 + (k ^ a)]; if (ch >= 0) kids[nk++] = ch; }
+    t.link[a].skip = skip_to;
+    t.link[a].hit = nk ? rec_of[kids[0]] : skip_to;
+    for (int i = 0; i < nk; i++) link_octant(d, a, kids[i], i + 1 < nk ? rec_of[kids[i + 1]] : skip_to, rec_of, out);
 }
 
 inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
 {
     if (!validate_scene(d, err)) return false;
-    H.tnodes.clear();
-    H.tnodes.reserve((size_t)d->n_node * 8);
-    for (int a = 0; a < 8; a++) {
-        size_t before = H.tnodes.size();
-        emit_ordered(d, a, 0, H.tnodes);
-        if (H.tnodes.size() - before != (size_t)d->n_node) { err = "scene: octree is not one connected pre-order tree"; return false; }
-        for (size_t i = before; i < H.tnodes.size(); i++) H.tnodes[i].skip -= (int32_t)before;  // links relative to the copy
+    // breadth-first record order: the nodes every ray visits (top levels) come first and are what the kernels keep in LDS
+    const int N = d->n_node;
+    std::vector<int32_t> rec_of((size_t)N, -1), order;
+    order.reserve((size_t)N);
+    rec_of[0] = 0;
+    order.push_back(0);
+    for (size_t head = 0; head < order.size(); head++) {
+        const int n = order[head];
+        for (int k = 0; k < 8; k++) {
+            const int ch = d->node_child[(size_t)n * 8 + k];
+            if (ch < 0) continue;
+            if (rec_of[ch] != -1) { err = "scene: octree node has two parents"; return false; }
+            rec_of[ch] = (int32_t)order.size();
+            order.push_back(ch);
+        }
     }
+    if ((int)order.size() != N) { err = "scene: octree is not one connected tree"; return false; }
+    H.tnodes.assign((size_t)N, TNode());
+    for (int n = 0; n < N; n++) {
+        TNode& t = H.tnodes[(size_t)rec_of[n]];
+        memset(&t, 0, sizeof t);
+        for (int k = 0; k < 3; k++) { t.bmin[k] = d->node_bbox[(size_t)n * 6 + k]; t.bmax[k] = d->node_bbox[(size_t)n * 6 + 3 + k]; }
+        bool inner = false;
+        for (int k = 0; k < 8; k++) if (d->node_child[(size_t)n * 8 + k] >= 0) inner = true;
+        t.first_ref = d->node_ent_off[n];
+        t.n_ref = inner ? -1 : d->node_ent_off[n + 1] - d->node_ent_off[n];
+        t.leaf_id = n;
+    }
+    for (int a = 0; a < 8; a++) link_octant(d, a, 0, N, rec_of, H.tnodes);
     H.refs.assign(d->node_ent_idx, d->node_ent_idx + d->node_ent_off[d->n_node]);
     H.tris.resize((size_t)d->n_tri);
     H.shade.resize((size_t)d->n_tri);

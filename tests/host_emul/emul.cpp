@@ -6,6 +6,7 @@
 // that lives in LDS on the GPU is a plain array here.
 #include <cstdlib>
 #define GI_HD static inline
+#define GI_HDM inline
 #include "../../gi_raytracer_amd/csrc/gi_layout.h"
 
 using namespace gi;
