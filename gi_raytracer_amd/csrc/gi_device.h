@@ -55,6 +55,11 @@ struct TriGeom {            // 80 B: what a ray-triangle test needs
     int32_t mat;
     uint32_t flags;         // bit0: interpolate vertex normals; bit1: alpha test always passes (opacity >= 1 or IOR != 1)
 };
+struct LeafTri {            // 80 B: the test record again, stored once per leaf reference in leaf order, so that a leaf's triangles
+    double p0[3], e1[3], e2[3];   // are consecutive in memory and no index has to be chased before the vertex data can be fetched
+    int32_t tri;            // triangle index (shading record, RNG key)
+    uint32_t matflags;      // material << 2 | flags
+};
 struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; };  // 96 B, read once per shaded hit
 struct Mat { double roughness, opacity, ior, diffuse[3], emissive[3]; };
 struct LightD { double pos[3], col[3], rad, dir[3], angle; };
@@ -72,6 +77,7 @@ struct HaltonDim { uint32_t P, n, off; float scale; };
 struct Scene {
     const TNode* tnodes;      // [n_node]
     const int32_t* leaf_refs;
+    const LeafTri* leaf_tris; // [n_refs], parallel to leaf_refs
     const TriGeom* tris;
     const TriShade* shade;
     const Mat* mats;
@@ -295,7 +301,8 @@ GI_HD bool box_contains(const double* bmin, const double* bmax, V3 p)  // includ
 GI_HD int dir_octant(const Ray& r) { return (r.d.x < 0.0 ? 1 : 0) | (r.d.z < 0.0 ? 2 : 0) | (r.d.y < 0.0 ? 4 : 0); }
 
 // ------------------------------------------------------------------------------------------------ triangle (include/entities.h:443-490)
-GI_HD bool tri_hit(const TriGeom& g, const Ray& ray, double& u, double& v, double& t)
+template <class Tri>
+GI_HD bool tri_hit(const Tri& g, const Ray& ray, double& u, double& v, double& t)
 {
     V3 edge1 = ld3(g.e1), edge2 = ld3(g.e2);
     V3 p = cross(ray.d, edge2);
@@ -364,13 +371,13 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
         // ---- its triangles
         bool term = false;
         for (int32_t k = 0; k < cnt; k++) {
-            const int32_t ti = S.leaf_refs[first + k];
-            const TriGeom& g = S.tris[ti];
+            const LeafTri& g = S.leaf_tris[first + k];
+            const int32_t ti = g.tri;
             double u, v, t;
             if (c) c->tri++;
             if (!tri_hit(g, ray, u, v, t)) continue;
-            if (!(g.flags & 2u)) {
-                const Mat& m = S.mats[g.mat];
+            if (!(g.matflags & 2u)) {
+                const Mat& m = S.mats[g.matflags >> 2];
                 if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
             }
             V3 hp = ray.o + t * ray.d;
@@ -416,13 +423,13 @@ GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double 
         }
         if (leaf < 0) break;
         for (int32_t k = 0; k < cnt; k++) {
-            const int32_t ti = S.leaf_refs[first + k];
-            const TriGeom& g = S.tris[ti];
+            const LeafTri& g = S.leaf_tris[first + k];
+            const int32_t ti = g.tri;
             double u, v, t;
             if (c) c->tri++;
             if (!tri_hit(g, ray, u, v, t)) continue;
-            if (!(g.flags & 2u)) {
-                const Mat& m = S.mats[g.mat];
+            if (!(g.matflags & 2u)) {
+                const Mat& m = S.mats[g.matflags >> 2];
                 if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
             }
             V3 hp = ray.o + t * ray.d;
@@ -718,7 +725,10 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         if (visible_nodes(S, N, sray, maxt, rng, (uint32_t)li, c)) {
             double d = dot(norm, normalize(lpos - h.pos));
             if (d < 0) d = 0;
-            double l = pow(d, (1.0 / roughness));
+            // pow(d, 1/roughness): exact shortcuts for the two exponents every constant-texture scene uses (x^1 = x; x^inf for a
+            // mirror: 0 below 1, 1 at 1), the general case through pow()
+            const double ex = (1.0 / roughness);
+            double l = ex == 1.0 ? d : (ex == INFINITY ? (d < 1.0 ? 0.0 : (d == 1.0 ? 1.0 : INFINITY)) : pow(d, ex));
             i = ld3(lt.col) * l * hfrac;
         }
     }

@@ -287,7 +287,7 @@ __device__ __forceinline__ void st_finish(const PathRec& p, uint32_t slot, const
 
 // refill free slots (q_free == nullptr: slots 0..n_free-1) with the next samples; new paths go to q_new
 __global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec* pool, unsigned long long* slot_sample, const uint32_t* q_free, uint32_t n_free,
-                                                      unsigned long long sample_end, uint32_t n_pix, StreamCtl* ctl, uint32_t* q_new)
+                                                      unsigned long long sample_begin, int s_begin, unsigned long long sample_end, uint32_t n_pix, StreamCtl* ctl, uint32_t* q_new)
 {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_free; i0 += gridDim.x * blockDim.x) {
@@ -305,12 +305,17 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec
         if (want) {
             int x = 0, ly = 0;
             // padding pixels of partial 8x8 tiles own sample ids but no work: skip to the next id (rare, per-lane atomic)
-            while (id < sample_end && !wf_pixel_xy(F, (uint32_t)(id % n_pix), x, ly)) id = atomicAdd(&ctl->next_sample, 1ull);
+            // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
+            uint32_t rel = (uint32_t)(id - sample_begin), srel = rel / n_pix;
+            while (id < sample_end && !wf_pixel_xy(F, rel - srel * n_pix, x, ly)) {
+                id = atomicAdd(&ctl->next_sample, 1ull);
+                rel = (uint32_t)(id - sample_begin); srel = rel / n_pix;
+            }
             if (id < sample_end) {
                 slot = q_free ? q_free[i] : i;
                 slot_sample[slot] = id;
                 uint32_t idx;
-                Ray ray = primary_ray(S, F, (int)(id / n_pix), x, global_row(F, ly), idx);
+                Ray ray = primary_ray(S, F, s_begin + (int)srel, x, global_row(F, ly), idx);
                 path_begin(pool[slot], ray, idx);
                 started = true;
             }
@@ -558,6 +563,7 @@ struct gi_ctx {
     Scene S{};
     DevBuf<TNode> d_tnodes;
     DevBuf<int32_t> d_refs;
+    DevBuf<LeafTri> d_leaf_tris;
     DevBuf<TriGeom> d_tris;
     DevBuf<TriShade> d_shade;
     DevBuf<Mat> d_mats;
@@ -666,12 +672,13 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, c->d_tnodes.upload(H.tnodes));
     HIP_TRY(c, c->d_refs.upload(H.refs));
+    HIP_TRY(c, c->d_leaf_tris.upload(H.leaf_tris));
     HIP_TRY(c, c->d_tris.upload(H.tris));
     HIP_TRY(c, c->d_shade.upload(H.shade));
     HIP_TRY(c, c->d_mats.upload(H.mats));
     HIP_TRY(c, c->d_lights.upload(H.lights));
     Scene& S = c->S;
-    S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
+    S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.leaf_tris = c->d_leaf_tris.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
     S.mats = c->d_mats.p; S.lights = c->d_lights.p;
     S.n_node = H.n_node; S.n_tri = H.n_tri; S.n_light = H.n_light;
     for (int k = 0; k < 3; k++) S.ambient[k] = H.ambient[k];
@@ -862,7 +869,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         for (;;) {
             if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
             if (samples_left && n_free > 0) {
-                hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_free, sample_end, n_pix, ctl, q_new);
+                hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_free, sample0, s0, sample_end, n_pix, ctl, q_new);
                 launches++;
             }
             // the trace pass needs n_new on the host for its bounds: read it back (regen is cheap, this is the only extra sync)

@@ -22,6 +22,7 @@ namespace gi {
 struct HostScene {
     std::vector<TNode> tnodes;
     std::vector<int32_t> refs;
+    std::vector<LeafTri> leaf_tris;
     std::vector<TriGeom> tris;
     std::vector<TriShade> shade;
     std::vector<Mat> mats;
@@ -192,6 +193,15 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         V3 fn = normalize(cross((p1 - p0), (p2 - p0)));                                          // include/entities.h:339
         s.fnorm[0] = fn.x; s.fnorm[1] = fn.y; s.fnorm[2] = fn.z;
     }
+    H.leaf_tris.resize(H.refs.size());
+    for (size_t r = 0; r < H.refs.size(); r++) {
+        const TriGeom& g = H.tris[(size_t)H.refs[r]];
+        LeafTri& lt = H.leaf_tris[r];
+        for (int k = 0; k < 3; k++) { lt.p0[k] = g.p0[k]; lt.e1[k] = g.e1[k]; lt.e2[k] = g.e2[k]; }
+        lt.tri = H.refs[r];
+        lt.matflags = ((uint32_t)g.mat << 2) | g.flags;
+    }
+    if (H.leaf_tris.empty()) H.leaf_tris.resize(1);
     H.mats.resize((size_t)d->n_mat);
     for (int i = 0; i < d->n_mat; i++) {
         const double* m = d->mats + (size_t)i * 9;

@@ -20,7 +20,7 @@ struct Emul {
     std::string err;
     void bind()
     {
-        S.tnodes = hs.tnodes.data(); S.leaf_refs = hs.refs.data(); S.tris = hs.tris.data(); S.shade = hs.shade.data();
+        S.tnodes = hs.tnodes.data(); S.leaf_refs = hs.refs.data(); S.leaf_tris = hs.leaf_tris.data(); S.tris = hs.tris.data(); S.shade = hs.shade.data();
         S.mats = hs.mats.data(); S.lights = hs.lights.data();
         S.n_node = hs.n_node; S.n_tri = hs.n_tri; S.n_light = hs.n_light;
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];
