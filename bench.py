@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--photons", type=int, default=200000)
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (-1: sized for ~20 s, 0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pool", type=int, default=0, help="path slots of the wavefront pool (0: library default)")
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "rounds", "megakernel"])
     args = ap.parse_args()
 
@@ -80,6 +81,8 @@ def main():
     rt = gi.RayTracer(local_rank).setScene(scene)
     rt.set_stream(torch.cuda.current_stream().cuda_stream)
     rt.set_render_mode(args.mode)
+    if args.pool > 0:
+        rt.set_pool_slots(args.pool)
     t0 = time.time()
     n_photons = 0
     if args.photons > 0 and scene.desc().n_light > 0:

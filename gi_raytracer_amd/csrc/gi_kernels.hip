@@ -142,6 +142,23 @@ __device__ __forceinline__ bool wf_pixel_xy(const Frame& F, uint32_t i, int& x, 
     return x < F.w && ly < F.local_rows;
 }
 
+// v-th pixel of the local frame in 8x8-tile order, partial tiles at the right / bottom edge included (no padding pixels)
+__device__ __forceinline__ void st_pixel_xy(const Frame& F, uint32_t v, int& x, int& ly)
+{
+    const uint32_t w = (uint32_t)F.w, rows = (uint32_t)F.local_rows;
+    const uint32_t tiles_x = (w + 7u) >> 3, rows_full = rows >> 3;
+    uint32_t r = v / (w * 8u);
+    if (r > rows_full) r = rows_full;
+    const uint32_t hr = r < rows_full ? 8u : (rows & 7u);
+    const uint32_t rem = v - r * w * 8u;
+    uint32_t tile = rem / (8u * hr);
+    uint32_t tw = 8u;
+    if (tile >= tiles_x - 1u) { tile = tiles_x - 1u; tw = w - 8u * (tiles_x - 1u); }
+    const uint32_t t = rem - tile * 8u * hr;
+    x = (int)(tile * 8u + t % tw);
+    ly = (int)(r * 8u + t / tw);
+}
+
 __global__ __launch_bounds__(GI_BLOCK) void k_wf_init(PixRec* pix, uint32_t n_pix)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
@@ -285,43 +302,23 @@ __device__ __forceinline__ void st_finish(const PathRec& p, uint32_t slot, const
     if (finished) q_free[at] = slot;
 }
 
-// refill free slots (q_free == nullptr: slots 0..n_free-1) with the next samples; new paths go to q_new
-__global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec* pool, unsigned long long* slot_sample, const uint32_t* q_free, uint32_t n_free,
-                                                      unsigned long long sample_begin, int s_begin, unsigned long long sample_end, uint32_t n_pix, StreamCtl* ctl, uint32_t* q_new)
+// refill the first n_start free slots (q_free == nullptr: slots 0..n_start-1) with samples id_base .. id_base + n_start - 1;
+// the new paths are q_new[0 .. n_start).  Sample ids are consecutive per lane, i.e. neighbouring pixels of one sample index.
+__global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec* pool, unsigned long long* slot_sample, const uint32_t* q_free, uint32_t n_start,
+                                                      unsigned long long id_base, unsigned long long sample_begin, int s_begin, uint32_t n_pix, uint32_t* q_new)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_free; i0 += gridDim.x * blockDim.x) {
-        const uint32_t i = i0 + lane;
-        const bool want = i < n_free;
-        // one atomic per wave: the lanes of a wave get consecutive sample ids (neighbouring pixels)
-        const unsigned long long mask = __ballot(want);
-        unsigned long long base = 0;
-        const int leader = __ffsll((long long)mask) - 1;
-        if (mask && (int)lane == leader) base = atomicAdd(&ctl->next_sample, (unsigned long long)__popcll(mask));
-        base = (unsigned long long)__shfl((long long)base, leader < 0 ? 0 : leader);
-        unsigned long long id = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-        bool started = false;
-        uint32_t slot = 0;
-        if (want) {
-            int x = 0, ly = 0;
-            // padding pixels of partial 8x8 tiles own sample ids but no work: skip to the next id (rare, per-lane atomic)
-            // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
-            uint32_t rel = (uint32_t)(id - sample_begin), srel = rel / n_pix;
-            while (id < sample_end && !wf_pixel_xy(F, rel - srel * n_pix, x, ly)) {
-                id = atomicAdd(&ctl->next_sample, 1ull);
-                rel = (uint32_t)(id - sample_begin); srel = rel / n_pix;
-            }
-            if (id < sample_end) {
-                slot = q_free ? q_free[i] : i;
-                slot_sample[slot] = id;
-                uint32_t idx;
-                Ray ray = primary_ray(S, F, s_begin + (int)srel, x, global_row(F, ly), idx);
-                path_begin(pool[slot], ray, idx);
-                started = true;
-            }
-        }
-        const uint32_t at = wave_append(&ctl->n_new, started);
-        if (started) q_new[at] = slot;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_start; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = q_free ? q_free[i] : i;
+        const unsigned long long id = id_base + i;
+        // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
+        const uint32_t rel = (uint32_t)(id - sample_begin), srel = rel / n_pix;
+        int x, ly;
+        st_pixel_xy(F, rel - srel * n_pix, x, ly);
+        slot_sample[slot] = id;
+        uint32_t idx;
+        Ray ray = primary_ray(S, F, s_begin + (int)srel, x, global_row(F, ly), idx);
+        path_begin(pool[slot], ray, idx);
+        q_new[i] = slot;
     }
 }
 
@@ -416,12 +413,32 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
     }
 }
 
+// the last stragglers of a chunk (paths bouncing inside closed specular geometry up to MAX_DEPTH): one lane runs one path to
+// its end instead of one nearly empty pass per remaining depth
+__global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+                                                        const uint32_t* q_cont, uint32_t n_in, double* lbuf)
+{
+    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = q_cont[i];
+        PathRec p = pool[slot];
+        while (p.depth <= GI_MAX_DEPTH) {
+            if (!stage_trace(S, p, seed, nullptr)) break;
+            const int fl = stage_shade(S, p, seed, nullptr);
+            if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_BLOCK, nullptr);
+            if (!(fl & ST_CONTINUE)) break;
+        }
+        const unsigned long long id = slot_sample[slot] - sample0;
+        lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
+    }
+}
+
 // fold samples [s0, s0 + ns) of every pixel into its running mean, in sample order (include/raytracer.h:131-147)
 __global__ __launch_bounds__(GI_BLOCK) void k_st_accum(Frame F, PixRec* pix, const double* lbuf, uint32_t n_pix, int ns, void* out, int out_f64, int32_t* out_spp)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
         int x, ly;
-        if (!wf_pixel_xy(F, i, x, ly)) continue;
+        st_pixel_xy(F, i, x, ly);
         PixRec r = pix[i];
         PixelState ps;
         ps.color = ld3(r.color); ps.lastCol = ld3(r.lastCol); ps.var = r.var; ps.samps = r.samps; ps.s = r.s;
@@ -591,7 +608,8 @@ struct gi_ctx {
     StreamCtl* h_ctl = nullptr;
     size_t lbuf_bytes_max = (size_t)16 << 30;
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
-    size_t pool_slots_max = (size_t)16 << 20;
+    size_t pool_slots_max = (size_t)64 << 20;   // 64 Mi paths in flight = 14 GiB of PathRec (the GPU has 288 GB)
+    uint32_t finish_threshold = 1u << 17;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0;
     int last_launches = 0;
@@ -737,8 +755,7 @@ static int render_megakernel(gi_ctx* c, const Frame& F, void* d_out, int out_is_
 
 static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
 {
-    const uint32_t tiles = (uint32_t)(((F.w + 7) >> 3) * ((F.local_rows + 7) >> 3));
-    const uint32_t n_pix = tiles * 64u;
+    const uint32_t n_pix = (uint32_t)F.w * (uint32_t)F.local_rows;   // valid pixels only, enumerated in 8x8-tile order (st_pixel_xy)
     int B = (int)std::min<size_t>(32, std::max<size_t>(1, c->pool_slots_max / n_pix));
     B = std::max(1, std::min(B, std::max(F.max_samples, 1)));
     const size_t slots = (size_t)n_pix * (size_t)B;
@@ -813,8 +830,7 @@ static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
 
 static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
 {
-    const uint32_t tiles = (uint32_t)(((F.w + 7) >> 3) * ((F.local_rows + 7) >> 3));
-    const uint32_t n_pix = tiles * 64u;
+    const uint32_t n_pix = (uint32_t)F.w * (uint32_t)F.local_rows;   // valid pixels only, enumerated in 8x8-tile order (st_pixel_xy)
     const int spp = F.max_samples;
     const uint32_t P = (uint32_t)std::min<size_t>(c->pool_slots_max, (size_t)n_pix * (size_t)spp);
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)));
@@ -834,11 +850,11 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     }
     if (!c->d_ctl.p) HIP_TRY(c, c->d_ctl.alloc(1));
     if (!c->h_ctl) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, sizeof(StreamCtl), hipHostMallocDefault));
-    static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0;
+    static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0, g_finish = 0;
     const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
     if (!g_trace) {
         g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace, lds_nodes, GI_TRACE_BLOCK);
-        g_shade = grid_for(c, (const void*)k_st_shade, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum);
+        g_shade = grid_for(c, (const void*)k_st_shade, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish);
     }
     hipStream_t st = c->stream;
     PathRec* pool = c->d_pool.p;
@@ -863,29 +879,27 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         HIP_TRY(c, hipStreamSynchronize(st));
         // pass 0: every slot is free
         uint32_t n_free = P, n_cont = 0;
+        unsigned long long next = sample0;
         const uint32_t* qf = nullptr;
         int ping = 0;
-        bool samples_left = true;
         for (;;) {
             if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
-            if (samples_left && n_free > 0) {
-                hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_free, sample0, s0, sample_end, n_pix, ctl, q_new);
+            const uint32_t n_new = (uint32_t)std::min<unsigned long long>(n_free, sample_end - next);
+            if (n_new > 0) {
+                hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_new, next, sample0, s0, n_pix, q_new);
                 launches++;
+                next += n_new;
             }
-            // the trace pass needs n_new on the host for its bounds: read it back (regen is cheap, this is the only extra sync)
-            HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-            const uint32_t n_new = c->h_ctl->n_new;
-            samples_left = c->h_ctl->next_sample < sample_end;
             if (n_new + n_cont == 0) break;
-            // reset the per-pass counters (next_sample is preserved)
-            StreamCtl hz = *c->h_ctl;
-            hz.n_new = 0; hz.n_cont = 0; hz.n_shade = 0; hz.n_gather = 0; hz.n_free = 0;
-            *c->h_ctl = hz;
-            HIP_TRY(c, hipMemcpyAsync(ctl, c->h_ctl, sizeof(StreamCtl), hipMemcpyHostToDevice, st));
-            uint32_t* qfree_out = q_free[ping];
             uint32_t* qcont_out = q_cont[ping];
             const uint32_t* qcont_in = q_cont[ping ^ 1];
+            if (next >= sample_end && n_new == 0 && n_cont <= c->finish_threshold) {
+                hipLaunchKernelGGL(k_st_finish, dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, qcont_in, n_cont, c->d_lbuf.p);
+                launches++;
+                break;
+            }
+            HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
+            uint32_t* qfree_out = q_free[ping];
             hipLaunchKernelGGL(k_st_trace, dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
                                q_shade, qfree_out, c->d_lbuf.p);
             hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
@@ -912,7 +926,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             }
             qf = qfree_out;
             ping ^= 1;
-            if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u next %llu/%llu\n", n_new, n_cont, n_free, c->h_ctl->n_gather, c->h_ctl->next_sample, sample_end);
+            if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u next %llu/%llu\n", n_new, n_cont, n_free, n_gather, next, sample_end);
         }
         hipLaunchKernelGGL(k_st_accum, dim3(g_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, ns, d_out, out_is_f64, d_spp);
         launches++;
