@@ -755,7 +755,8 @@ static int render_megakernel(gi_ctx* c, const Frame& F, void* d_out, int out_is_
 
 static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
 {
-    const uint32_t n_pix = (uint32_t)F.w * (uint32_t)F.local_rows;   // valid pixels only, enumerated in 8x8-tile order (st_pixel_xy)
+    const uint32_t tiles = (uint32_t)(((F.w + 7) >> 3) * ((F.local_rows + 7) >> 3));
+    const uint32_t n_pix = tiles * 64u;   // padded to whole 8x8 tiles (wf_pixel_xy)
     int B = (int)std::min<size_t>(32, std::max<size_t>(1, c->pool_slots_max / n_pix));
     B = std::max(1, std::min(B, std::max(F.max_samples, 1)));
     const size_t slots = (size_t)n_pix * (size_t)B;

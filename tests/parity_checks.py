@@ -84,7 +84,7 @@ def check_render(rt, scene, w, h, spp, photons, adaptive=False):
     else:
         img, nspp = rt.run(w, h, min_samples=spp, max_samples=spp, want_spp=True)
         ref = o.render(w, h, spp)
-        assert (nspp == spp).all()
+        assert (nspp == spp).all(), (np.unique(nspp, return_counts=True), float(img.mean()))
     rmse = float(np.sqrt(((img - ref["lin"]) ** 2).mean()))
     assert rmse < RMSE_TOL, rmse
     return rmse, img, ref["lin"]
