@@ -36,7 +36,9 @@ def algorithmic_bytes_per_sample(counters, n_samples, spp):
     t = counters[2] / n_samples
     hh = counters[3] / n_samples
     p = counters[4] / n_samples
-    return 32 * v + 36 * t + 96 * hh + 36 * p + 12.0 / spp, {"V": v, "T": t, "H": hh, "P": p}
+    mix = {"V": v, "T": t, "H": hh, "P": p, "V_trace": counters[0] / n_samples, "V_shadow": counters[1] / n_samples,
+           "T_shadow": counters[8] / n_samples, "T_trace": (counters[2] - counters[8]) / n_samples}
+    return 32 * v + 36 * t + 96 * hh + 36 * p + 12.0 / spp, mix
 
 
 def main():
@@ -101,6 +103,7 @@ def main():
     row_index = [torch.as_tensor(pc.stripe_rows(h, stripe_h, r, world), device=dev) for r in range(world)] if rank == 0 else None
 
     kernel_ms = []
+    stage_ms = []
 
     def step(record):
         rt.run_device(p, local.data_ptr(), f64=False)
@@ -111,6 +114,7 @@ def main():
                     frame[row_index[r]] = gathered[r][: len(row_index[r])]
         if record:
             kernel_ms.append(rt.last_render_ms()[0])   # HIP events on the launch stream (synchronises on the second event)
+            stage_ms.append(rt.last_stage_ms())        # HIP events around every launch, summed per pipeline stage
 
     def sync():
         if world > 1:
@@ -176,12 +180,26 @@ def main():
             out["config"]["rmse_vs_oracle_on_cpu_rows"] = rmse
         if bytes_per_sample is None:
             # per-sample mix measured by the oracle on this workload (profiles/r01_notes.md); used when the CPU leg is skipped
-            bytes_per_sample, mix = 32 * 93.0 + 36 * 62.6 + 96 * 0.95 + 36 * 70.0 + 12.0 / spp, None
+            bytes_per_sample, mix = 32 * 99.1 + 36 * 56.1 + 96 * 0.90 + 36 * 71.9 + 12.0 / spp, None
         local_samples = rows * w * spp
-        achieved = bytes_per_sample * local_samples / (kernel_ms_avg * 1e-3) / 1e9
+        stages = {k: float(np.mean([s[k] for s in stage_ms])) for k in stage_ms[0]} if stage_ms else {}
+        pipeline_ms = sum(stages.values()) if sum(stages.values()) > 0 else kernel_ms_avg   # megakernel mode: one launch
+        achieved = bytes_per_sample * local_samples / (pipeline_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "k_render", "kernel_ms": kernel_ms_avg, "algorithmic_bytes_per_sample": bytes_per_sample,
-                           "per_sample_mix": mix}
+                           "traffic": None,
+                           "kernel": "streaming wavefront pipeline of one frame: k_st_regen, k_st_trace, k_st_shade, k_st_gkeys + 2 radix sorts, k_st_gather, k_st_finish, k_st_accum"
+                                     if args.mode == "wavefront" else args.mode,
+                           "kernel_ms": pipeline_ms, "frame_ms_event_to_event": kernel_ms_avg, "stage_ms": stages,
+                           "algorithmic_bytes_per_sample": bytes_per_sample, "per_sample_mix": mix}
+        if stages and mix is not None and sum(stages.values()) > 0:
+            dom = max(stages, key=stages.get)
+            # algorithmic bytes of the stages that walk the scene octree (SURVEY 8(d) terms restricted to that stage)
+            stage_bytes = {"trace": 32 * mix["V_trace"] + 36 * mix["T_trace"], "shade": 32 * mix["V_shadow"] + 36 * mix["T_shadow"] + 96 * mix["H"],
+                           "gather": 36 * mix["P"]}
+            if dom in stage_bytes:
+                a = stage_bytes[dom] * local_samples / (stages[dom] * 1e-3) / 1e9
+                out["roofline"]["dominant"] = {"kernel": "k_st_" + dom, "ms_per_frame": stages[dom], "algorithmic_bytes_per_sample": stage_bytes[dom],
+                                               "achieved": a, "frac": a / HBM_PEAK_GBS}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -54,7 +54,7 @@ _LIB = None
 # every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
-    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_pool_slots", "gi_last_render_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
+    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_light", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
@@ -84,6 +84,7 @@ def lib():
     L.gi_set_render_mode.argtypes = [vp, C.c_int]
     L.gi_set_pool_slots.argtypes = [vp, C.c_int64]
     L.gi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), _ip]
+    L.gi_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.gi_set_counters.argtypes = [vp, C.c_int]
     L.gi_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gi_trace.argtypes = [vp, C.c_int32, _dp, _ip, _ip, _dp]
@@ -334,6 +335,13 @@ class RayTracer:
         ms, n = C.c_float(), C.c_int32()
         self._check(self.L.gi_last_render_ms(self.h, C.byref(ms), C.byref(n)), "last_render_ms")
         return ms.value, n.value
+
+    STAGES = ("regen", "trace", "shade", "sort", "gather", "finish", "accum", "other")
+
+    def last_stage_ms(self):
+        out = (C.c_float * 8)()
+        self._check(self.L.gi_last_stage_ms(self.h, out), "last_stage_ms")
+        return dict(zip(self.STAGES, [float(v) for v in out]))
 
     def set_counters(self, on):
         self.L.gi_set_counters(self.h, 1 if on else 0)

@@ -607,6 +607,12 @@ struct gi_ctx {
     DevBuf<unsigned char> d_sort_tmp;
     StreamCtl* h_ctl = nullptr;
     size_t lbuf_bytes_max = (size_t)16 << 30;
+    // per-stage device time of the last streaming frame (HIP events around every launch, same stream)
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_stage;        // stage id of event pair k (events 2k, 2k+1)
+    size_t ev_used = 0;
+    bool stage_timing = true;
+    float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
     size_t pool_slots_max = (size_t)64 << 20;   // 64 Mi paths in flight = 14 GiB of PathRec (the GPU has 288 GB)
     uint32_t finish_threshold = 1u << 17;
@@ -665,6 +671,7 @@ void gi_destroy(gi_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_wfcnt) (void)hipHostFree(c->h_wfcnt);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -829,6 +836,23 @@ static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     return GI_OK;
 }
 
+enum { STG_REGEN = 0, STG_TRACE, STG_SHADE, STG_SORT, STG_GATHER, STG_FINISH, STG_ACCUM, STG_OTHER };
+static void stage_begin(gi_ctx* c, int stage)
+{
+    if (!c->stage_timing) return;
+    if (c->ev_used + 2 > c->ev_pool.size()) {
+        for (int k = 0; k < 2; k++) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->ev_pool.push_back(e); }
+    }
+    c->ev_stage.push_back(stage);
+    (void)hipEventRecord(c->ev_pool[c->ev_used], c->stream);
+}
+static void stage_end(gi_ctx* c)
+{
+    if (!c->stage_timing || c->ev_used + 2 > c->ev_pool.size()) return;
+    (void)hipEventRecord(c->ev_pool[c->ev_used + 1], c->stream);
+    c->ev_used += 2;
+}
+
 static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
 {
     const uint32_t n_pix = (uint32_t)F.w * (uint32_t)F.local_rows;   // valid pixels only, enumerated in 8x8-tile order (st_pixel_xy)
@@ -866,6 +890,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     uint32_t* q_gather = c->d_qs[4].p;
     uint32_t* q_free[2] = {c->d_qs[5].p, c->d_q[0].p};
     int launches = 0;
+    c->ev_used = 0; c->ev_stage.clear();
     HIP_TRY(c, hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(k_wf_init, dim3(g_init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
     launches++;
@@ -887,7 +912,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
             const uint32_t n_new = (uint32_t)std::min<unsigned long long>(n_free, sample_end - next);
             if (n_new > 0) {
-                hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_new, next, sample0, s0, n_pix, q_new);
+                stage_begin(c, STG_REGEN); hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_new, next, sample0, s0, n_pix, q_new); stage_end(c);
                 launches++;
                 next += n_new;
             }
@@ -895,16 +920,16 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             uint32_t* qcont_out = q_cont[ping];
             const uint32_t* qcont_in = q_cont[ping ^ 1];
             if (next >= sample_end && n_new == 0 && n_cont <= c->finish_threshold) {
-                hipLaunchKernelGGL(k_st_finish, dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, qcont_in, n_cont, c->d_lbuf.p);
+                stage_begin(c, STG_FINISH); hipLaunchKernelGGL(k_st_finish, dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, qcont_in, n_cont, c->d_lbuf.p); stage_end(c);
                 launches++;
                 break;
             }
             HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
             uint32_t* qfree_out = q_free[ping];
-            hipLaunchKernelGGL(k_st_trace, dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
-                               q_shade, qfree_out, c->d_lbuf.p);
-            hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
-                               qfree_out, c->d_lbuf.p);
+            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(k_st_trace, dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+                               q_shade, qfree_out, c->d_lbuf.p); stage_end(c);
+            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(k_st_shade, dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
+                               qfree_out, c->d_lbuf.p); stage_end(c);
             launches += 2;
             HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
@@ -912,24 +937,28 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             if (c->S.n_pnode > 0 && n_gather > 0) {
                 int bits = 1;
                 while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
-                hipLaunchKernelGGL(k_st_gkeys, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p);
+                stage_begin(c, STG_SORT); hipLaunchKernelGGL(k_st_gkeys, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p); stage_end(c);
                 size_t tmp_bytes = c->d_sort_tmp.n;
+                stage_begin(c, STG_SORT);
                 HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
-                hipLaunchKernelGGL(k_st_gather, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather);
+                stage_end(c);
+                stage_begin(c, STG_GATHER); hipLaunchKernelGGL(k_st_gather, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather); stage_end(c);
                 launches += 3;
             }
             n_cont = c->h_ctl->n_cont;
             n_free = c->h_ctl->n_free;
             if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
                 size_t tmp_bytes = c->d_sort_tmp.n;
+                stage_begin(c, STG_SORT);
                 HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, 0, 27, st));
+                stage_end(c);
                 launches++;
             }
             qf = qfree_out;
             ping ^= 1;
             if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u next %llu/%llu\n", n_new, n_cont, n_free, n_gather, next, sample_end);
         }
-        hipLaunchKernelGGL(k_st_accum, dim3(g_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, ns, d_out, out_is_f64, d_spp);
+        stage_begin(c, STG_ACCUM); hipLaunchKernelGGL(k_st_accum, dim3(g_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, ns, d_out, out_is_f64, d_spp); stage_end(c);
         launches++;
     }
     HIP_TRY(c, hipGetLastError());
@@ -976,8 +1005,22 @@ int gi_last_render_ms(gi_ctx* c, float* ms, int32_t* n_launches)
         HIP_TRY(c, hipEventSynchronize(c->ev1));
         HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
     }
+    for (int k = 0; k < 8; k++) c->stage_ms[k] = 0;
+    for (size_t k = 0; k + 1 < c->ev_used + 1 && k / 2 < c->ev_stage.size() && k + 1 < c->ev_pool.size() && k < c->ev_used; k += 2) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, c->ev_pool[k], c->ev_pool[k + 1]) == hipSuccess) c->stage_ms[c->ev_stage[k / 2]] += t;
+    }
     if (ms) *ms = c->last_ms;
     if (n_launches) *n_launches = c->last_launches;
+    return GI_OK;
+}
+
+int gi_last_stage_ms(gi_ctx* c, float* out8)
+{
+    if (!c || !out8) return GI_E_INVALID;
+    int rc = gi_last_render_ms(c, nullptr, nullptr);
+    if (rc) return rc;
+    for (int k = 0; k < 8; k++) out8[k] = c->stage_ms[k];
     return GI_OK;
 }
 

@@ -101,6 +101,9 @@ int gi_set_render_mode(gi_ctx*, int mode);
 int gi_set_pool_slots(gi_ctx*, int64_t slots);
 /* Device time in ms of the render kernel(s) of the last gi_render_* call, measured with hipEvents on the launch stream. */
 int gi_last_render_ms(gi_ctx*, float* ms, int32_t* n_launches);
+/* Device time per pipeline stage of the last render, summed over its launches (HIP events around every launch):
+ * [0] regenerate, [1] trace, [2] shade, [3] sorts (+ key kernels), [4] gather, [5] finish, [6] accumulate, [7] other.      */
+int gi_last_stage_ms(gi_ctx*, float* out8);
 /* Work counters of the last render (when enabled with gi_set_counters(ctx,1)): node visits in trace, node visits in
  * visible, triangle tests, shaded hits, photon candidates, trace calls, shadow rays, gathers.                              */
 int gi_set_counters(gi_ctx*, int enable);

@@ -524,7 +524,7 @@ struct ONode { Box box; int child[8]; std::vector<int> ents; bool leaf() const {
 struct PNode { Box box; int first_child; std::vector<int> ph; };
 struct Photon { V3 origin, dir, col; };
 
-struct Counters { int64_t v_trace = 0, v_shadow = 0, tri = 0, shaded = 0, pcand = 0, traces = 0, shadows = 0, gathers = 0; };
+struct Counters { int64_t v_trace = 0, v_shadow = 0, tri = 0, shaded = 0, pcand = 0, traces = 0, shadows = 0, gathers = 0, tri_shadow = 0; };
 
 }  // namespace
 
@@ -700,7 +700,7 @@ struct gio_ctx {
         while (!hit && k != cand.size()) {
             const Entity& e = ents[cand[k].second];
             Hit h;
-            if (c) c->tri++;
+            if (c) { c->tri++; c->tri_shadow++; }
             if (ent_intersect(e, ray, h) && (rng.draw(P_SHADOW_ALPHA | (light_index << 8), (uint32_t)cand[k].first, (uint32_t)cand[k].second) < mat_alpha(mats[e.mat]) || mats[e.mat].IOR != 1)) {
                 double t_shadow = len2(h.pos - ray.origin);
                 hit = (t_shadow < mt) && (t_shadow > 0);
@@ -1304,13 +1304,13 @@ static int render_rows(gio_ctx* c, int w, int h, int n_rows, const int32_t* rows
 #pragma omp critical(gio_counters)
         {
             total.v_trace += local.v_trace; total.v_shadow += local.v_shadow; total.tri += local.tri; total.shaded += local.shaded;
-            total.pcand += local.pcand; total.traces += local.traces; total.shadows += local.shadows; total.gathers += local.gathers;
+            total.pcand += local.pcand; total.traces += local.traces; total.shadows += local.shadows; total.gathers += local.gathers; total.tri_shadow += local.tri_shadow;
         }
     }
     if (rng_mode == GIO_RNG_CHAIN) c->chain_state = chain.state;
     if (counters) {
         counters[0] = total.v_trace; counters[1] = total.v_shadow; counters[2] = total.tri; counters[3] = total.shaded;
-        counters[4] = total.pcand; counters[5] = total.traces; counters[6] = total.shadows; counters[7] = total.gathers;
+        counters[4] = total.pcand; counters[5] = total.traces; counters[6] = total.shadows; counters[7] = total.gathers; counters[8] = total.tri_shadow;
     }
     return 0;
 }

@@ -70,8 +70,8 @@ int gio_gather(gio_ctx*, int n, const double* q, double* res3, int32_t* n_cand);
 /* RayTracer::run pixel loop (include/raytracer.h:74-160) over rows [y0,y1) of a w x h frame.
  * out_lin: [h][w][3] linear (pre-gamma, unclamped) running-mean radiance, rows outside [y0,y1) untouched.
  * out_u8 (optional): [h][w][3] gamma 2.2 / clamp / (int)(255 c) as Image::setPixel (include/image.h:14-16).
- * out_spp (optional): [h][w] samples taken.  counters (optional) [8]: node visits (trace), node visits (shadow),
- * triangle tests, shaded hits, photon candidates, trace calls, shadow rays, gathers.
+ * out_spp (optional): [h][w] samples taken.  counters (optional) [9]: node visits (trace), node visits (shadow),
+ * triangle tests (all), shaded hits, photon candidates, trace calls, shadow rays, gathers, triangle tests in shadow rays.
  * chain_predraws: GIO_RNG_CHAIN only -- drand() draws discarded before the pixel loop (RayTracer::run's two
  * subrand() calls, include/raytracer.h:87-90).                                                               */
 int gio_render(gio_ctx*, int w, int h, int y0, int y1, int min_samples, int max_samples, double noise_thresh,

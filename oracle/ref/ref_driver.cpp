@@ -581,6 +581,31 @@ static int cmd_chain(const char* scn, const std::string& out, int W, int H, int 
     return 0;
 }
 
+// ---------------------------------------------------------------- timing of the reference's own pixel loop (calibration of the CPU baseline)
+static int cmd_time(const char* scn, int W, int H, int spp, int nphotons, int threads)
+{
+    omp_set_num_threads(threads);
+    Loaded L;
+    load(L, scn);
+    L.rt.photons = nphotons;
+    L.rt.min_samples = spp;
+    L.rt.max_samples = spp;
+    Halton_sampler sampler;
+    sampler.init_faure();
+    Halton_enum he(W, H);
+    L.scene->rebuild();
+    auto t0 = std::chrono::high_resolution_clock::now();
+    L.rt.tracePhotons(5, L.rt.photons, sampler, he);
+    L.rt._photon_map->rebuild();
+    auto t1 = std::chrono::high_resolution_clock::now();
+    L.rt.start();
+    L.rt.run(W, H);   // scene and photon map are valid: this is the pixel loop (plus Halton table init)
+    auto t2 = std::chrono::high_resolution_clock::now();
+    double tp = std::chrono::duration<double>(t1 - t0).count(), tr = std::chrono::duration<double>(t2 - t1).count();
+    fprintf(stderr, "REFTIME threads %d frame %dx%dx%d photons %d: photon_s %.3f render_s %.3f Msamples/s %.4f\n", threads, W, H, spp, nphotons, tp, tr, (double)W * H * spp / tr / 1e6);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: see header comment\n"); return 2; }
@@ -588,6 +613,7 @@ int main(int argc, char** argv)
     if (cmd == "halton") return cmd_halton(argv[2]);
     if (cmd == "kat") return cmd_kat(argv[2]);
     if (cmd == "scene" && argc >= 7) return cmd_scene(argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
+    if (cmd == "time" && argc >= 8) return cmd_time(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
     if (cmd == "chain" && argc >= 9) return cmd_chain(argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), argv[8]);
     fprintf(stderr, "bad arguments\n");
     return 2;

@@ -233,7 +233,7 @@ class Oracle:
         y1 = h if y1 is None else y1
         lin = np.zeros((h, w, 3)); spp = np.zeros((h, w), np.int32)
         u8 = np.zeros((h, w, 3), np.uint8) if want_u8 else None
-        cnt = np.zeros(8, np.int64) if want_counters else None
+        cnt = np.zeros(9, np.int64) if want_counters else None
         r = self.L.gio_render(self.h, w, h, y0, y1, min_samples, max_samples, noise_thresh, rng_mode, C.c_uint64(seed), chain_predraws,
                               n_threads, _ptr(lin, c_dp), _ptr(u8, C.POINTER(C.c_uint8)), _ptr(spp, c_ip),
                               _ptr(cnt, C.POINTER(C.c_int64)))
@@ -248,7 +248,7 @@ class Oracle:
     def render_rows(self, w, h, rows, spp, seed=DEFAULT_SEED, n_threads=0):
         """Full-width rows `rows` of a w x h frame at fixed spp; returns (lin [h][w][3] with only those rows filled, counters[8])."""
         rows = np.ascontiguousarray(rows, np.int32)
-        lin = np.zeros((h, w, 3)); cnt = np.zeros(8, np.int64)
+        lin = np.zeros((h, w, 3)); cnt = np.zeros(9, np.int64)
         r = self.L.gio_render_rows(self.h, w, h, len(rows), _ptr(rows, c_ip), spp, spp, 0.0, C.c_uint64(seed), n_threads, _ptr(lin, c_dp),
                                    _ptr(cnt, C.POINTER(C.c_int64)))
         assert r == 0
