@@ -26,7 +26,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-STRIPE_H = 16
 
 
 def algorithmic_bytes_per_sample(counters, n_samples, spp):
@@ -60,6 +59,7 @@ def main():
     import torch
     import gi_raytracer_amd as gi
     import parity_checks as pc
+    from gi_raytracer_amd.sharding import STRIPE_H, FrameGather
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,22 +96,15 @@ def main():
     stripe_h = STRIPE_H if world > 1 else h
     p = rt.params(w, h, stripe_h=stripe_h, rank=rank, world=world, min_samples=spp, max_samples=spp)
     rows = rt.local_rows(p)
-    max_rows = max(len(pc.stripe_rows(h, stripe_h, r, world)) for r in range(world))
-    local = torch.zeros((max_rows, w, 3), dtype=torch.float32, device=dev)
-    gathered = [torch.zeros_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
-    frame = torch.zeros((h, w, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-    row_index = [torch.as_tensor(pc.stripe_rows(h, stripe_h, r, world), device=dev) for r in range(world)] if rank == 0 else None
+    fg = FrameGather(torch, dist, w, h, stripe_h, rank, world, dev, torch.float32)
+    assert rows == len(fg.rows[rank])
 
     kernel_ms = []
     stage_ms = []
 
     def step(record):
-        rt.run_device(p, local.data_ptr(), f64=False)
-        if world > 1:
-            dist.gather(local, gathered, dst=0)
-            if rank == 0:
-                for r in range(world):
-                    frame[row_index[r]] = gathered[r][: len(row_index[r])]
+        rt.run_device(p, fg.local.data_ptr(), f64=False)
+        fg.gather()                                    # N > 1: one RCCL gather of the stripes to rank 0 (inside the timed region)
         if record:
             kernel_ms.append(rt.last_render_ms()[0])   # HIP events on the launch stream (synchronises on the second event)
             stage_ms.append(rt.last_stage_ms())        # HIP events around every launch, summed per pipeline stage
@@ -142,7 +135,7 @@ def main():
     if rank == 0:
         samples_per_step = w * h * spp
         value = samples_per_step * args.steps / elapsed / 1e6
-        img = (frame if world > 1 else local[:h]).cpu().numpy()
+        img = fg.frame.cpu().numpy()
         out = {
             "metric": "Msamples/sec (primary+path rays) at 1080p", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,

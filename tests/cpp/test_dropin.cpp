@@ -1,0 +1,45 @@
+// tests/cpp/test_dropin.cpp -- the reference's main.cpp flow (Camera -> RayTracer -> Octree -> loadScene -> setScene -> start ->
+// run -> getImage) compiled against the drop-in headers.  argv[1] = .scn, argv[2] = "gpu" to actually render (GPU box),
+// otherwise only the host side (loader, Octree::rebuild, API surface, copyability) is exercised.
+#include <cstdio>
+#include <cstring>
+#include "../../include/gi/raytracer.h"
+#include "../../include/gi/sceneLoader.h"
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 2;
+    Camera camera(gi::dvec3(10, 5, 0), gi::dvec3(0, 0, 0));        // main.cpp:28
+    RayTracer raytracer(camera);                                   // main.cpp:30
+    Octree* scene = new Octree();                                  // main.cpp:34
+    loadScene(scene, raytracer, argv[1]);                          // main.cpp:36-39
+    raytracer.setScene(scene);                                     // main.cpp:41
+    RayTracer copy = raytracer;                                    // gui.h:19 / viewer.h:16 pass it by value
+    scene->rebuild();
+    printf("lights %zu photons %d samples %d..%d up %.6f %.6f %.6f\n", scene->lights.size(), copy.photons, copy.min_samples, copy.max_samples,
+           copy._camera.up.x, copy._camera.up.y, copy._camera.up.z);
+    if (scene->lights.size()) printf("light0 angle %.12f\n", scene->lights[0]->angle);
+    // programmatic scene as the mesh generators build it (entities.h:721-738): two triangles and a light
+    Octree* quad = new Octree();
+    texture white(gi::dvec3(1, 1, 1)), black(gi::dvec3(0, 0, 0));
+    Material mat(&white, &black, 1, 1);
+    quad->push_back(new triangle(vertex(gi::dvec3(0, 0, 0)), vertex(gi::dvec3(1, 0, 0)), vertex(gi::dvec3(0, 0, 1)), mat));
+    quad->push_back(new triangle(vertex(gi::dvec3(1, 0, 0)), vertex(gi::dvec3(1, 0, 1)), vertex(gi::dvec3(0, 0, 1)), mat));
+    quad->push_back(new Light(gi::dvec3(0, 5, 0), gi::dvec3(0, 0, 0), gi::dvec3(4, 4, 4), .05));
+    quad->rebuild();
+    printf("quad valid %d\n", (int)quad->valid);
+    if (argc > 2 && strcmp(argv[2], "gpu") == 0) {
+        copy.min_samples = copy.max_samples = 4;
+        copy.photons = 2000;
+        copy.start();
+        copy.run(64, 36);                                          // viewer.h:52-56
+        if (!copy.last_error().empty()) { printf("error: %s\n", copy.last_error().c_str()); return 1; }
+        auto img = copy.getImage();
+        double sum = 0;
+        for (int y = 0; y < 36; y++) for (int x = 0; x < 64; x++) { gi::dvec3 px = img->getPixel(x, y); sum += px.x + px.y + px.z; }
+        double lin = 0;
+        for (float v : copy.linear()) lin += v;
+        printf("rendered 64x36: 8-bit sum %.6f linear mean %.9f\n", sum, lin / copy.linear().size());
+    }
+    return 0;
+}

@@ -135,9 +135,4 @@ def check_stripes(rt, scene, w, h, spp, world, stripe_h):
     assert np.array_equal(frame, full)
 
 
-def stripe_rows(h, stripe_h, rank, world):
-    rows = []
-    n_stripes = (h + stripe_h - 1) // stripe_h
-    for k in range(rank, n_stripes, world):
-        rows.extend(range(k * stripe_h, min((k + 1) * stripe_h, h)))
-    return np.array(rows, int)
+from gi_raytracer_amd.sharding import stripe_rows  # noqa: E402  (re-exported for the tests)

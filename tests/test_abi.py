@@ -48,5 +48,6 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "gi_oracle" not in src and "oracle_lib" not in src and "libgi_emul" not in src, f
-    for f in os.listdir(os.path.join(ROOT, "include")):
-        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower().replace("oracle/", "")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "oracle" not in open(os.path.join(dirpath, f)).read().lower(), f
