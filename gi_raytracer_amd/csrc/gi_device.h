@@ -368,17 +368,16 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
             break;
         }
         if (leaf < 0) break;
-        // ---- its triangles
+        // ---- its triangles, two records in flight at a time (the fetch of the second overlaps the test of the first)
         bool term = false;
-        for (int32_t k = 0; k < cnt; k++) {
-            const LeafTri& g = S.leaf_tris[first + k];
+        auto test = [&](const LeafTri& g) {
             const int32_t ti = g.tri;
             double u, v, t;
             if (c) c->tri++;
-            if (!tri_hit(g, ray, u, v, t)) continue;
+            if (!tri_hit(g, ray, u, v, t)) return;
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 2];
-                if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) return;
             }
             V3 hp = ray.o + t * ray.d;
             double d2 = len2(hp - ray.o);
@@ -388,6 +387,12 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
                 intersected = true;
                 if (box_contains(lmin, lmax, hp)) term = true;
             }
+        };
+        for (int32_t k = 0; k < cnt; k += 2) {
+            const LeafTri g0 = S.leaf_tris[first + k];
+            const LeafTri g1 = S.leaf_tris[first + (k + 1 < cnt ? k + 1 : k)];
+            test(g0);
+            if (k + 1 < cnt) test(g1);
         }
         if (term) break;
     }
@@ -509,6 +514,29 @@ GI_HD int32_t gather_find_leaf(const Scene& S, V3 pos)
     }
     return node;
 }
+// Visit every candidate photon of a leaf's range list.  Positions are fetched four at a time before any of them is used, so the
+// four loads are in flight together instead of one L2 round trip per photon (the loop is latency-bound otherwise).
+template <class F>
+GI_HD void for_each_candidate(const Scene& S, const PRange* ranges, int n_ranges, F&& f)
+{
+    for (int r = 0; r < n_ranges; r++) {
+        const PRange rg = ranges[r];
+        const double* base = S.ph_pos + (size_t)rg.first * 3;
+        for (int32_t j = 0; j < rg.count; j += 4) {
+            const int32_t last = rg.count - 1;
+            const int32_t j1 = j + 1 < last ? j + 1 : last, j2 = j + 2 < last ? j + 2 : last, j3 = j + 3 < last ? j + 3 : last;
+            const double* p0 = base + (size_t)j * 3;
+            const double* p1 = base + (size_t)j1 * 3;
+            const double* p2 = base + (size_t)j2 * 3;
+            const double* p3 = base + (size_t)j3 * 3;
+            const V3 a = v3(p0[0], p0[1], p0[2]), b = v3(p1[0], p1[1], p1[2]), cc = v3(p2[0], p2[1], p2[2]), d = v3(p3[0], p3[1], p3[2]);
+            f(rg.first + j, a);
+            if (j + 1 <= last) f(rg.first + j + 1, b);
+            if (j + 2 <= last) f(rg.first + j + 2, cc);
+            if (j + 3 <= last) f(rg.first + j + 3, d);
+        }
+    }
+}
 GI_HD V3 gather_in_leaf(const Scene& S, int32_t node, V3 pos, V3 dir, float* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
 {
     V3 res = v3(0, 0, 0);
@@ -527,34 +555,26 @@ GI_HD V3 gather_in_leaf(const Scene& S, int32_t node, V3 pos, V3 dir, float* hea
     Heap h;
     h.hp = heap_mem; h.stride = heap_stride; h.n = 0;
     float tau = 0;
-    for (int r = 0; r < n_ranges; r++) {
-        const PRange rg = ranges[r];
-        const double* pp = S.ph_pos + (size_t)rg.first * 3;
-        for (int32_t k = 0; k < rg.count; k++, pp += 3) {
-            float key = (float)len2(v3(pp[0], pp[1], pp[2]) - pos);
-            if (h.n < GI_GATHER_K) { heap_push(h, key); tau = h.hp[0]; }
-            else if (key < tau) { heap_replace_root(h, key); tau = h.hp[0]; }
-        }
-    }
+    for_each_candidate(S, ranges, n_ranges, [&](int32_t, V3 pp) {
+        float key = (float)len2(pp - pos);
+        if (h.n < GI_GATHER_K) { heap_push(h, key); tau = h.hp[0]; }
+        else if (key < tau) { heap_replace_root(h, key); tau = h.hp[0]; }
+    });
     const int K = ncand < GI_GATHER_K ? ncand : GI_GATHER_K;
     // pass 2
     V3 s_lt = v3(0, 0, 0), s_eq = v3(0, 0, 0);
     int c_lt = 0, c_eq = 0;
     double r_eq = 0;
-    for (int r = 0; r < n_ranges; r++) {
-        const PRange rg = ranges[r];
-        const double* pp = S.ph_pos + (size_t)rg.first * 3;
-        for (int32_t k = 0; k < rg.count; k++, pp += 3) {
-            double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
-            float key = (float)d2;
-            if (key <= tau) {
-                const double* dc = S.ph_dircol + (size_t)(rg.first + k) * 6;
-                V3 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
-                if (key < tau) { s_lt = s_lt + contrib; c_lt++; }
-                else { s_eq = s_eq + contrib; c_eq++; r_eq = d2 > r_eq ? d2 : r_eq; }
-            }
+    for_each_candidate(S, ranges, n_ranges, [&](int32_t idx, V3 pp) {
+        double d2 = len2(pp - pos);
+        float key = (float)d2;
+        if (key <= tau) {
+            const double* dc = S.ph_dircol + (size_t)idx * 6;
+            V3 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
+            if (key < tau) { s_lt = s_lt + contrib; c_lt++; }
+            else { s_eq = s_eq + contrib; c_eq++; r_eq = d2 > r_eq ? d2 : r_eq; }
         }
-    }
+    });
     const int need = K - c_lt;  // >= 1: the heap root itself is a candidate with key == tau
     double r2;
     if (c_eq <= need) { res = s_lt + s_eq; r2 = r_eq; }
