@@ -366,7 +366,7 @@ __device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& 
     return (oct << 24) | (m << 6) | db;
 }
 
-__global__ __launch_bounds__(GI_SHADE_BLOCK) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+__global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
 {
     const LdsNodes N = stage_nodes_in_lds(S);
