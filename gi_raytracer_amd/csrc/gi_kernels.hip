@@ -614,7 +614,7 @@ struct gi_ctx {
     bool stage_timing = true;
     float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
-    size_t pool_slots_max = (size_t)64 << 20;   // 64 Mi paths in flight = 14 GiB of PathRec (the GPU has 288 GB)
+    size_t pool_slots_max = (size_t)1 << 30;    // upper bound on paths in flight; the actual pool is also bounded by free HBM (render_streaming)
     uint32_t finish_threshold = 1u << 17;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0;
@@ -857,7 +857,21 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
 {
     const uint32_t n_pix = (uint32_t)F.w * (uint32_t)F.local_rows;   // valid pixels only, enumerated in 8x8-tile order (st_pixel_xy)
     const int spp = F.max_samples;
-    const uint32_t P = (uint32_t)std::min<size_t>(c->pool_slots_max, (size_t)n_pix * (size_t)spp);
+    // Paths in flight: as many as fit -- the whole frame when HBM allows (1080p x 256 spp = 531 M paths = 119 GB of PathRec on a
+    // 288 GB part).  More paths per pass = fewer passes and, above all, better-sorted (more coherent) queues.
+    size_t slots_budget = c->pool_slots_max;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t held = c->d_pool.n * sizeof(PathRec) + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7;   // ours, re-usable
+            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24;   // record, sample id, 13 queue / key words, sort scratch
+            const size_t lbuf = (size_t)n_pix * (size_t)std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)) * 24;
+            const size_t avail = (size_t)((double)(free_b + held) * 0.80);
+            if (avail > lbuf) slots_budget = std::min(slots_budget, (avail - lbuf) / per_slot);
+            else slots_budget = std::min<size_t>(slots_budget, 1u << 20);
+        }
+    }
+    const uint32_t P = (uint32_t)std::max<size_t>(64, std::min<size_t>(std::min<size_t>(slots_budget, 0xfffffff0u), (size_t)n_pix * (size_t)spp));
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)));
     if (c->d_pool.n < P) HIP_TRY(c, c->d_pool.alloc(P));
     if (c->d_slot_sample.n < P) HIP_TRY(c, c->d_slot_sample.alloc(P));

@@ -97,7 +97,8 @@ int gi_render_host(gi_ctx*, const gi_render_params*, void* h_out_lin, int out_is
  * path queues in HBM; fixed-spp frames refill finished slots with new samples, adaptive frames run in synchronous rounds),
  * 1 = megakernel (one lane keeps one pixel, whole path in registers), 2 = wavefront in synchronous rounds always.            */
 int gi_set_render_mode(gi_ctx*, int mode);
-/* Upper bound on paths in flight in the wavefront pipeline (224 B each; default 16 Mi).                                      */
+/* Upper bound on paths in flight in the wavefront pipeline (224 B each).  Default: as many as 80 % of the free HBM holds,
+ * up to the whole frame (1080p x 256 spp = 531 M paths = 119 GB).                                                           */
 int gi_set_pool_slots(gi_ctx*, int64_t slots);
 /* Device time in ms of the render kernel(s) of the last gi_render_* call, measured with hipEvents on the launch stream. */
 int gi_last_render_ms(gi_ctx*, float* ms, int32_t* n_launches);

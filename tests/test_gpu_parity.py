@@ -74,7 +74,7 @@ def test_wavefront_small_pool_many_rounds(setup):
         rt.set_render_mode("rounds")
         c = rt.run(40, 30, min_samples=6, max_samples=6)           # synchronous rounds of 2 samples
     finally:
-        rt.set_pool_slots(16 << 20)
+        rt.set_pool_slots(1 << 30)
         rt.set_render_mode("wavefront")
     assert np.array_equal(a, b) and np.array_equal(a, c)
 
