@@ -53,12 +53,13 @@ struct alignas(128) TNode { // 128 B = one L2 line: a scene-octree node, stored 
 struct TriGeom {            // 80 B: what a ray-triangle test needs
     double p0[3], e1[3], e2[3];
     int32_t mat;
-    uint32_t flags;         // bit0: interpolate vertex normals; bit1: alpha test always passes (opacity >= 1 or IOR != 1)
+    uint32_t flags;         // bit0: interpolate vertex normals; bit1: alpha test always passes (opacity >= 1 or IOR != 1);
+                            // bit2: analytic sphere (p0 = centre, e1[0] = radius)
 };
 struct LeafTri {            // 80 B: the test record again, stored once per leaf reference in leaf order, so that a leaf's triangles
     double p0[3], e1[3], e2[3];   // are consecutive in memory and no index has to be chased before the vertex data can be fetched
     int32_t tri;            // triangle index (shading record, RNG key)
-    uint32_t matflags;      // material << 2 | flags
+    uint32_t matflags;      // material << 3 | flags
 };
 struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; };  // 96 B, read once per shaded hit
 struct Mat { double roughness, opacity, ior, diffuse[3], emissive[3]; };
@@ -322,6 +323,34 @@ GI_HD bool tri_hit(const Tri& g, const Ray& ray, double& u, double& v, double& t
 
 struct HitRec { V3 pos; double u, v; int32_t tri; };
 
+// Entity::intersect for the two kinds on this path: triangle (include/entities.h:443-490, barycentric u, v) and analytic sphere
+// (include/entities.h:60-101; u, v = its texture coordinates).  hp = hit point.
+template <class Tri>
+GI_HD bool ent_hit(const Tri& g, uint32_t flags, const Ray& ray, double& u, double& v, V3& hp)
+{
+    if (!(flags & 4u)) {
+        double t;
+        if (!tri_hit(g, ray, u, v, t)) return false;
+        hp = ray.o + t * ray.d;
+        return true;
+    }
+    const V3 pos = ld3(g.p0);
+    const double rad = g.e1[0];
+    const V3 oc = ray.o - pos;
+    const double dt = dot(ray.d, oc);
+    const double r = (dt * dt - len2(oc) + rad * rad);
+    if (r < 0) return false;
+    const double sr = sqrt(r);
+    const double t_1 = -1 * dt - sr, t_2 = -1 * dt + sr;
+    if (t_1 < 0 && t_2 < 0) return false;
+    if ((t_1 < t_2 && t_1 > 0) || t_2 < 0) hp = ray.o + ray.d * t_1;
+    else hp = ray.o + ray.d * t_2;
+    const V3 dd = (pos - hp) / rad;
+    v = .5 + asin(dd.y) / GI_PI;
+    u = .5 + atan2(dd.z, dd.x) / (2 * GI_PI);
+    return true;
+}
+
 // Where node records come from: plain global memory here; gi_kernels.hip adds a source that serves the first nodes from LDS.
 struct NodeView { double bmin[3], bmax[3]; int32_t first_ref, n_ref, hit, skip; };
 struct GlobalNodes {
@@ -372,14 +401,14 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
         bool term = false;
         auto test = [&](const LeafTri& g) {
             const int32_t ti = g.tri;
-            double u, v, t;
+            double u, v;
+            V3 hp;
             if (c) c->tri++;
-            if (!tri_hit(g, ray, u, v, t)) return;
+            if (!ent_hit(g, g.matflags, ray, u, v, hp)) return;
             if (!(g.matflags & 2u)) {
-                const Mat& m = S.mats[g.matflags >> 2];
+                const Mat& m = S.mats[g.matflags >> 3];
                 if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) return;
             }
-            V3 hp = ray.o + t * ray.d;
             double d2 = len2(hp - ray.o);
             if (!intersected || d2 < best_d2) {
                 best.pos = hp; best.u = u; best.v = v; best.tri = ti;
@@ -430,14 +459,14 @@ GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double 
         for (int32_t k = 0; k < cnt; k++) {
             const LeafTri& g = S.leaf_tris[first + k];
             const int32_t ti = g.tri;
-            double u, v, t;
+            double u, v;
+            V3 hp;
             if (c) c->tri++;
-            if (!tri_hit(g, ray, u, v, t)) continue;
+            if (!ent_hit(g, g.matflags, ray, u, v, hp)) continue;
             if (!(g.matflags & 2u)) {
-                const Mat& m = S.mats[g.matflags >> 2];
+                const Mat& m = S.mats[g.matflags >> 3];
                 if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
             }
-            V3 hp = ray.o + t * ray.d;
             double ts = len2(hp - ray.o);
             if ((ts < mt) && (ts > 0)) return false;
         }
@@ -661,6 +690,7 @@ GI_HD void secondary_ray(const Ray& ray, const Mat& m, V3& norm, double sx, doub
 GI_HD V3 shading_normal(const Scene& S, const HitRec& h)  // include/entities.h:478-485
 {
     const TriShade& sh = S.shade[h.tri];
+    if (S.tris[h.tri].flags & 4u) return normalize(h.pos - ld3(sh.n0));   // sphere: normalize(intersect - pos), include/entities.h:84
     if (S.tris[h.tri].flags & 1u) return (1 - h.u - h.v) * ld3(sh.n0) + h.u * ld3(sh.n1) + h.v * ld3(sh.n2);
     return ld3(sh.fnorm);
 }

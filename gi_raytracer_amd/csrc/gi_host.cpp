@@ -143,6 +143,7 @@ struct gih_scene {
     // entities (triangles), insertion order = Octree::_root._entities order
     std::vector<double> tri_pos, tri_nrm, tri_uv;
     std::vector<int32_t> tri_mat;
+    std::vector<int32_t> ent_kind;   // 0 triangle, 1 sphere (centre = vertex 0, radius = vertex 1 x)
     std::vector<double> mats;     // 9 per material
     std::vector<double> lights;   // 11 per light
     gih_settings st;
@@ -187,6 +188,13 @@ struct gih_scene {
     Aabb triangle_box(int t) const
     {
         Aabb b;
+        if (ent_kind[t] == 1) {   // sphere::boundingBox, include/entities.h:103-106
+            const D3 c = vert(t, 0);
+            const double rad = vert(t, 1).x;
+            b.lo = mk(c.x + rad * -1, c.y + rad * -1, c.z + rad * -1);
+            b.hi = mk(c.x + rad * 1, c.y + rad * 1, c.z + rad * 1);
+            return b;
+        }
         b.lo = mk(INFINITY, INFINITY, INFINITY); b.hi = mk(-INFINITY, -INFINITY, -INFINITY);
         for (int k = 0; k < 3; k++) {
             const D3 v = vert(t, k);
@@ -203,6 +211,19 @@ struct gih_scene {
     // triangle::intersect(BoundingBox), include/entities.h:522-528
     bool triangle_in_cell(int t, const Aabb& cell) const
     {
+        if (ent_kind[t] == 1) {   // sphere::intersect(BoundingBox), include/entities.h:108-141: squared distance centre-box <= rad^2
+            const D3 c = vert(t, 0);
+            const double rad = vert(t, 1).x;
+            double sq = 0.0;
+            for (int ax = 0; ax < 3; ax++) {
+                const double v = comp(c, ax), lo = comp(cell.lo, ax), hi = comp(cell.hi, ax);
+                double out = 0;
+                if (v < lo) { const double val = (lo - v); out += val * val; }
+                if (v > hi) { const double val = (v - hi); out += val * val; }
+                sq += out;
+            }
+            return sq <= (rad * rad);
+        }
         Aabb g;
         g.lo = mk(cell.lo.x - kEps, cell.lo.y - kEps, cell.lo.z - kEps);
         g.hi = mk(cell.hi.x + kEps, cell.hi.y + kEps, cell.hi.z + kEps);
@@ -215,7 +236,15 @@ struct gih_scene {
         for (int k = 0; k < 3; k++) { tri_nrm.push_back(n[k].x); tri_nrm.push_back(n[k].y); tri_nrm.push_back(n[k].z); }
         for (int k = 0; k < 6; k++) tri_uv.push_back(uv[k]);
         tri_mat.push_back(mat);
+        ent_kind.push_back(0);
         tree_valid = false;
+    }
+    void push_sphere(D3 c, double rad, int mat)   // new sphere(pos, rad, mat), include/entities.h:55-58
+    {
+        const D3 p[3] = {c, mk(rad, 0, 0), mk(0, 0, 0)}, z[3] = {mk(0, 0, 0), mk(0, 0, 0), mk(0, 0, 0)};
+        const double uv[6] = {0, 0, 0, 0, 0, 0};
+        push_triangle(p, z, uv, mat);
+        ent_kind.back() = 1;
     }
 
     // ---------------------------------------------------------------- Octree::Node::partition as an emitter of pre-order arrays
@@ -453,7 +482,14 @@ struct gih_scene {
                 fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %d\n", &pos.x, &pos.y, &pos.z, &size.x, &size.y, &size.z, &rot.x, &rot.y, &rot.z, &mat);
                 if (mat < 0 || mat >= n_mats_here) { err = "box: material index out of range"; rc = -2; break; }
                 add_box(pos, size, rot, mat_base + mat);
-            } else if (strcmp(word, "sphere") == 0 || strcmp(word, "heightFog") == 0) {
+            } else if (strcmp(word, "sphere") == 0) {
+                D3 pos;
+                double rad = 0;
+                int mat = 0;
+                fscanf(f, "%lf %lf %lf %lf %d\n", &pos.x, &pos.y, &pos.z, &rad, &mat);
+                if (mat < 0 || mat >= n_mats_here) { err = "sphere: material index out of range"; rc = -2; break; }
+                push_sphere(pos, rad, mat_base + mat);
+            } else if (strcmp(word, "heightFog") == 0) {
                 err = std::string("keyword not supported by this build: ") + word;
                 rc = -2;
                 break;
@@ -525,6 +561,14 @@ int gih_add_triangles(gih_scene* s, int32_t n, const double* pos, const double* 
     return 0;
 }
 
+int gih_add_sphere(gih_scene* s, const double* centre3, double radius, int32_t mat_idx)
+{
+    if (!s || !centre3) return -1;
+    if (mat_idx < 0 || mat_idx >= (int)(s->mats.size() / 9)) { s->err = "add_sphere: material index out of range"; return -2; }
+    s->push_sphere(mk(centre3[0], centre3[1], centre3[2]), radius, mat_idx);
+    return 0;
+}
+
 int gih_add_light(gih_scene* s, const double* pos3, const double* col3, double rad)
 {
     if (!s || !pos3 || !col3) return -1;
@@ -573,6 +617,7 @@ int gih_get_scene_desc(const gih_scene* s, gi_scene_desc* d)
     d->n_node = (int32_t)(s->node_bbox.size() / 6);
     d->node_bbox = s->node_bbox.data(); d->node_child = s->node_child.data();
     d->node_ent_off = s->node_ent_off.data(); d->node_ent_idx = s->node_ent_idx.data();
+    d->ent_kind = s->ent_kind.data();
     return 0;
 }
 

@@ -21,7 +21,8 @@ void gih_scene_destroy(gih_scene*);
 const char* gih_last_error(const gih_scene*);
 
 /* replaces loadScene + loadOBJ (include/sceneLoader.cpp:12-185, include/meshLoader.cpp:18-99): same keyword set and the
- * same word-wise tokenising; vertices, normals and uvs are rounded to float as the reference's loader does.  A `mat` line
+ * same word-wise tokenising (keywords colorTex, mat, multiMat, mesh, sphere, box, light, photons, samples, ambient, camera);
+ * vertices, normals and uvs are rounded to float as the reference's loader does.  A `mat` line
  * without its 5th number gets IOR 1.0 (the reference leaves it uninitialised).  Missing mesh files are skipped.
  * Returns 0, or -1 when the .scn itself cannot be opened.                                                            */
 int gih_load_scn(gih_scene*, const char* path);
@@ -29,6 +30,7 @@ int gih_load_scn(gih_scene*, const char* path);
 /* programmatic construction = Octree::push_back (include/octree.cpp:25-50) */
 int gih_add_material(gih_scene*, const double* mat9);                 /* returns the material index */
 int gih_add_triangles(gih_scene*, int32_t n, const double* pos, const double* nrm, const double* uv, const int32_t* mat_idx);
+int gih_add_sphere(gih_scene*, const double* centre3, double radius, int32_t mat_idx);   /* new sphere(pos, rad, mat) */
 int gih_add_light(gih_scene*, const double* pos3, const double* col3, double rad);
 int gih_set_ambient(gih_scene*, const double* rgb3);
 

@@ -110,8 +110,11 @@ inline bool validate_scene(const gi_scene_desc* d, std::string& err)
     if (!d || d->n_tri < 0 || d->n_mat <= 0 || d->n_light < 0 || d->n_node <= 0) { err = "scene: bad counts"; return false; }
     if (d->n_tri && (!d->tri_pos || !d->tri_nrm || !d->tri_mat)) { err = "scene: null triangle tables"; return false; }
     if (!d->mats || !d->node_bbox || !d->node_child || !d->node_ent_off || (d->n_light && !d->lights)) { err = "scene: null tables"; return false; }
-    for (int i = 0; i < d->n_tri; i++)
+    for (int i = 0; i < d->n_tri; i++) {
         if (d->tri_mat[i] < 0 || d->tri_mat[i] >= d->n_mat) { err = "scene: material index out of range"; return false; }
+        if (d->ent_kind && d->ent_kind[i] != 0 && d->ent_kind[i] != 1) { err = "scene: unknown entity kind"; return false; }
+    }
+    if (d->n_mat >= (1 << 28)) { err = "scene: too many materials"; return false; }
     const int nref = d->node_ent_off[d->n_node];
     if (d->node_ent_off[0] != 0 || nref < 0 || (nref && !d->node_ent_idx)) { err = "scene: bad leaf reference table"; return false; }
     for (int n = 0; n < d->n_node; n++) {
@@ -185,13 +188,16 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         g.e2[0] = e2.x; g.e2[1] = e2.y; g.e2[2] = e2.z;
         g.mat = d->tri_mat[i];
         const double* m = d->mats + (size_t)g.mat * 9;
-        const bool smooth = len2(ld3(N)) > 0 && len2(ld3(N + 3)) > 0 && len2(ld3(N + 6)) > 0;   // include/entities.h:478
+        const bool sphere = d->ent_kind && d->ent_kind[i] == 1;
+        const bool smooth = !sphere && len2(ld3(N)) > 0 && len2(ld3(N + 3)) > 0 && len2(ld3(N + 6)) > 0;   // include/entities.h:478
         const bool always = (m[1] * 1.0 >= 1.0) || (m[2] != 1);                                  // include/raytracer.h:455
-        g.flags = (smooth ? 1u : 0u) | (always ? 2u : 0u);
+        g.flags = (smooth ? 1u : 0u) | (always ? 2u : 0u) | (sphere ? 4u : 0u);
+        if (sphere) { g.e1[0] = P[3]; g.e1[1] = 0; g.e1[2] = 0; g.e2[0] = 0; g.e2[1] = 0; g.e2[2] = 0; }   // centre in p0, radius in e1[0]
         TriShade& s = H.shade[i];
         for (int k = 0; k < 3; k++) { s.n0[k] = N[k]; s.n1[k] = N[3 + k]; s.n2[k] = N[6 + k]; }
-        V3 fn = normalize(cross((p1 - p0), (p2 - p0)));                                          // include/entities.h:339
+        V3 fn = sphere ? v3(0, 0, 0) : normalize(cross((p1 - p0), (p2 - p0)));                   // include/entities.h:339
         s.fnorm[0] = fn.x; s.fnorm[1] = fn.y; s.fnorm[2] = fn.z;
+        if (sphere) { s.n0[0] = P[0]; s.n0[1] = P[1]; s.n0[2] = P[2]; }                         // centre, for the shading normal
     }
     H.leaf_tris.resize(H.refs.size());
     for (size_t r = 0; r < H.refs.size(); r++) {
@@ -199,7 +205,7 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         LeafTri& lt = H.leaf_tris[r];
         for (int k = 0; k < 3; k++) { lt.p0[k] = g.p0[k]; lt.e1[k] = g.e1[k]; lt.e2[k] = g.e2[k]; }
         lt.tri = H.refs[r];
-        lt.matflags = ((uint32_t)g.mat << 2) | g.flags;
+        lt.matflags = ((uint32_t)g.mat << 3) | g.flags;
     }
     if (H.leaf_tris.empty()) H.leaf_tris.resize(1);
     H.mats.resize((size_t)d->n_mat);

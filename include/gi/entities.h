@@ -1,6 +1,6 @@
 // include/gi/entities.h -- mirrors include/entities.h of the reference for the entity kinds of this path: Entity (interface
 // data), vertex, triangle.  Intersection is not done on the host any more: RayTracer::trace / visible run on the GPU over the
-// flattened tables (include/gi_hip.h); sphere / cone are not on this path.
+// flattened tables (include/gi_hip.h); cone and the mesh generators are not on this path.
 #pragma once
 #include <array>
 #include "material.h"
@@ -11,6 +11,10 @@ struct Entity {
     gi::dvec3 pos = gi::dvec3(0, 0, 0);
     gi::dvec3 rot = gi::dvec3(0, 0, 0);
     Material material;
+};
+struct sphere : Entity {    // include/entities.h:51-142: analytic sphere, intersected on the GPU like the triangles
+    double rad;
+    sphere(gi::dvec3 position, double radius, const Material& m) : Entity(m), rad(radius) { pos = position; }
 };
 struct vertex {
     gi::dvec3 pos = gi::dvec3(0, 0, 0);

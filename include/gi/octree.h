@@ -31,12 +31,17 @@ class Octree {
         gih_scene* s = fresh ? fresh : _h;
         if (fresh) {
             for (Entity* e : _entities) {
-                triangle* t = dynamic_cast<triangle*>(e);
-                if (!t) { gih_scene_destroy(fresh); throw std::runtime_error("Octree::rebuild: only triangle entities are on the GPU path"); }
                 gi::dvec2 uv0(0, 0);
-                const gi::dvec3 d = t->material.diffuse->get(uv0), em = t->material.emissive->get(uv0);
-                const double m[9] = {t->material.roughness, t->material.opacity, t->material.IOR, d.x, d.y, d.z, em.x, em.y, em.z};
+                const gi::dvec3 d = e->material.diffuse->get(uv0), em = e->material.emissive->get(uv0);
+                const double m[9] = {e->material.roughness, e->material.opacity, e->material.IOR, d.x, d.y, d.z, em.x, em.y, em.z};
                 const int mi = gih_add_material(s, m);
+                if (sphere* sp = dynamic_cast<sphere*>(e)) {
+                    const double c[3] = {sp->pos.x, sp->pos.y, sp->pos.z};
+                    gih_add_sphere(s, c, sp->rad, mi);
+                    continue;
+                }
+                triangle* t = dynamic_cast<triangle*>(e);
+                if (!t) { gih_scene_destroy(fresh); throw std::runtime_error("Octree::rebuild: only triangle and sphere entities are on the GPU path"); }
                 double pos[9], nrm[9], uv[6];
                 for (int k = 0; k < 3; k++) {
                     const vertex& v = t->vertices[k];

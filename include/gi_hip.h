@@ -29,7 +29,7 @@ typedef struct gi_ctx gi_ctx;
 
 /* Flattened scene = what Octree holds after push_back()/rebuild() (include/octree.h:39-64, include/octree.cpp:25-119). */
 typedef struct gi_scene_desc {
-    int32_t n_tri;
+    int32_t n_tri;           /* number of entities (triangles, and spheres when ent_kind is given)                          */
     const double* tri_pos;   /* [n_tri][3][3] vertex positions          (triangle::vertices[k].pos, include/entities.h:331) */
     const double* tri_nrm;   /* [n_tri][3][3] vertex normals (all-zero row = flat shading, include/entities.h:478)          */
     const double* tri_uv;    /* [n_tri][3][2] texture coordinates                                                           */
@@ -45,6 +45,9 @@ typedef struct gi_scene_desc {
     const int32_t* node_child;   /* [n_node][8] node index or -1 (null child)                                               */
     const int32_t* node_ent_off; /* [n_node+1] range of node_ent_idx owned by the node (leaves only)                        */
     const int32_t* node_ent_idx; /* [node_ent_off[n_node]] triangle indices in Node::_entities order                        */
+    /* entity kinds (include/entities.h): NULL = all triangles; else [n_tri] with 0 = triangle, 1 = analytic sphere
+     * (include/entities.h:51-142) whose centre is tri_pos[i][0] and radius tri_pos[i][1].x (normals / uvs unused)          */
+    const int32_t* ent_kind;
 } gi_scene_desc;
 
 /* Photon set + linearised PhotonMap (include/photonMap.h:13-49, include/photon.h:5-15). */

@@ -22,6 +22,8 @@ SCENES = {
     "test_scene": (f"{REF}/examples/test_scene/test.scn", 96, 96, 0),
     "cornell": (f"{REF}/scenes/cornell/test.scn", 64, 48, 5000),
     "caustics": (f"{REF}/scenes/caustics/caustics.scn", 64, 48, 20000),
+    # our own scene file with the `sphere` keyword (analytic spheres: mirror, glass, glossy), run through the reference
+    "spheres": (f"{ROOT}/scenes/spheres/spheres_opaque.scn", 48, 36, 4000),
 }
 CHAINS = {
     # name: (scene, W, H, spp, photons, mode)
@@ -30,6 +32,9 @@ CHAINS = {
     "chain_cornell_lin": (f"{REF}/scenes/cornell/test.scn", 32, 32, 4, 2000, "lin"),
     "chain_cornell_run": (f"{REF}/scenes/cornell/test.scn", 32, 32, 4, 2000, "run"),
     "chain_test_scene_lin": (f"{REF}/examples/test_scene/test.scn", 32, 32, 2, 0, "lin"),
+    # all four spheres, one of them half transparent (stochastic alpha test: exact only on the pinned chain)
+    "chain_spheres_lin": (f"{ROOT}/scenes/spheres/spheres.scn", 40, 30, 4, 1500, "lin"),
+    "chain_spheres_run": (f"{ROOT}/scenes/spheres/spheres.scn", 40, 30, 4, 1500, "run"),
 }
 
 

@@ -8,7 +8,8 @@ import gi_raytracer_amd as gi
 import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCN = {"test_scene": "scenes/test_scene/test.scn", "cornell": "scenes/cornell/test.scn", "caustics": "scenes/caustics/caustics.scn"}
+SCN = {"test_scene": "scenes/test_scene/test.scn", "cornell": "scenes/cornell/test.scn", "caustics": "scenes/caustics/caustics.scn",
+       "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn"}
 
 # float tolerance of the path (north_star: pixel RMSE < 1e-4 on linear radiance); measured values are ~1e-16
 RMSE_TOL = 1e-4
@@ -20,7 +21,7 @@ def load_scene(name):
 
 def oracle_for(scene):
     t, st = scene.tables(), scene.settings
-    o = ol.Oracle().set_scene(t["tri_pos"], t["tri_nrm"], t["tri_uv"], t["tri_mat"], t["mats"], t["lights"][:, :7], t["ambient"])
+    o = ol.Oracle().set_scene(t["tri_pos"], t["tri_nrm"], t["tri_uv"], t["tri_mat"], t["mats"], t["lights"][:, :7], t["ambient"], kind=t["ent_kind"])
     o.set_camera(list(st.cam_pos), list(st.cam_up), list(st.cam_forward), st.sensor_diag, st.focal_dist)
     return o.build_octree()
 

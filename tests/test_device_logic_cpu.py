@@ -8,10 +8,10 @@ import emul_lib as el
 import parity_checks as pc
 
 
-@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics"])
+@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque"])
 def setup(request, golden):
     scene = pc.load_scene(request.param)
-    return request.param, scene, el.EmulRayTracer().setScene(scene), golden("scene_" + request.param)
+    return request.param, scene, el.EmulRayTracer().setScene(scene), golden("scene_" + request.param.replace("_opaque", ""))
 
 
 def test_halton_device_tables(golden):
@@ -63,3 +63,12 @@ def test_stripe_sharding_is_exact(setup):
 
 def test_gather_resolves_float_key_ties_exactly():
     pc.check_gather_float_ties(el.EmulRayTracer)
+
+
+def test_render_with_stochastic_alpha_and_glass_matches_oracle():
+    """scenes/spheres/spheres.scn: mirror, glass (refraction + Fresnel lobe choice), glossy Phong lobe, a half-transparent sphere
+    (alpha test draws keyed by leaf and entity), non-zero ambient."""
+    scene = pc.load_scene("spheres")
+    rt = el.EmulRayTracer().setScene(scene)
+    rmse, img, ref = pc.check_render(rt, scene, 40, 30, 6, 1500)
+    assert rmse < 1e-12 and img.mean() > 0.01

@@ -20,10 +20,10 @@ def rt0():
     return gi.RayTracer(0)
 
 
-@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics"])
+@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque"])
 def setup(request, golden):
     scene = pc.load_scene(request.param)
-    return request.param, scene, gi.RayTracer(0).setScene(scene), golden("scene_" + request.param)
+    return request.param, scene, gi.RayTracer(0).setScene(scene), golden("scene_" + request.param.replace("_opaque", ""))
 
 
 def test_halton_device_tables(rt0, golden):
@@ -114,6 +114,17 @@ def test_empty_and_edge_inputs(setup):
     assert (img == 0.5).all()
     # 1x1 frame
     assert rt.run(1, 1, min_samples=1, max_samples=1).shape == (1, 1, 3)
+
+
+@pytest.mark.parametrize("mode", ["wavefront", "rounds", "megakernel"])
+def test_render_with_stochastic_alpha_and_glass_matches_oracle(mode):
+    """scenes/spheres/spheres.scn: analytic spheres -- mirror, glass (refraction + Fresnel lobe choice), glossy Phong lobe, a
+    half-transparent one (alpha test draws keyed by leaf and entity) -- and non-zero ambient."""
+    scene = pc.load_scene("spheres")
+    rt = gi.RayTracer(0).setScene(scene)
+    rt.set_render_mode(mode)
+    rmse, img, ref = pc.check_render(rt, scene, 80, 60, 8, 3000)
+    assert rmse < 1e-9 and img.mean() > 0.01
 
 
 def test_no_photon_map_gather_is_zero():

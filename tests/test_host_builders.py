@@ -7,11 +7,12 @@ import gi_raytracer_amd as gi
 import parity_checks as pc
 
 
-@pytest.mark.parametrize("name", ["test_scene", "cornell", "caustics"])
+@pytest.mark.parametrize("name", ["test_scene", "cornell", "caustics", "spheres_opaque"])
 def test_loader_octree_photon_map_identical_to_reference(golden, name):
-    fx = golden("scene_" + name)
+    fx = golden("scene_" + name.replace("_opaque", ""))
     s = pc.load_scene(name)
     t = s.tables()
+    assert np.array_equal(t["ent_kind"], fx["ent_kind"])
     assert np.array_equal(t["tri_pos"], fx["tri_pos"]) and np.array_equal(t["tri_nrm"], fx["tri_nrm"]) and np.array_equal(t["tri_uv"], fx["tri_uv"])
     rows, ref = t["mats"][t["tri_mat"]], fx["tri_mat"].copy()
     # a `mat` line without IOR: the reference reads an uninitialised double (observed 0.575 in caustics); we define 1.0

@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib as ol
 
-SCENES = ["test_scene", "cornell", "caustics"]
+SCENES = ["test_scene", "cornell", "caustics", "spheres"]
 
 
 def P(a):
@@ -130,7 +130,8 @@ def test_photon_octree_and_gather_identical(scene):
 
 
 # ------------------------------------------------------------------ whole frames on the pinned RNG chain (a-1, a-2, a-10, f1)
-@pytest.mark.parametrize("name", ["chain_test_scene_lin", "chain_caustics_lin", "chain_cornell_lin", "chain_caustics_run", "chain_cornell_run"])
+@pytest.mark.parametrize("name", ["chain_test_scene_lin", "chain_caustics_lin", "chain_cornell_lin", "chain_caustics_run", "chain_cornell_run",
+                                  "chain_spheres_lin", "chain_spheres_run"])
 def test_whole_frame_matches_reference_bit_for_bit(golden, name):
     """The reference's frame (its own RayTracer::run for *_run; radiance() per sample for *_lin) on a pinned time() and
     one OpenMP thread, including tracePhotons and the photon-map build, reproduced by the oracle's chain RNG mode."""
