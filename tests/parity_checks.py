@@ -68,7 +68,8 @@ def check_emission(rt, scene, n):
     on, otries = o.emit_photons(n, 5, ol.RNG_COUNTER, rt.seed)
     oph = o.get_photons()
     assert len(ph) == on and tries == otries
-    np.testing.assert_allclose(ph, oph, rtol=1e-12, atol=1e-15)
+    # same photons; refraction through glass amplifies the <=1 ulp differences between OCML and glibc sin/cos/acos
+    np.testing.assert_allclose(ph, oph, rtol=1e-9, atol=1e-12)
     return o, ph
 
 
