@@ -96,6 +96,7 @@ struct Scene {
     const HaltonDim* hdims;   // [256]
     const uint16_t* htable;
     int32_t n_node, n_tri, n_light, n_pnode, n_photon;
+    int32_t has_spheres;      // 0: triangles only
     double ambient[3];
 };
 
@@ -331,10 +332,10 @@ struct HitRec { V3 pos; double u, v; int32_t tri; };
 
 // Entity::intersect for the two kinds on this path: triangle (include/entities.h:443-490, barycentric u, v) and analytic sphere
 // (include/entities.h:60-101).  hp = hit point.
-template <class Tri>
+template <bool SPH, class Tri>
 GI_HD bool ent_hit(const Tri& g, uint32_t flags, const Ray& ray, double& u, double& v, V3& hp)
 {
-    if (!(flags & 4u)) {
+    if (!SPH || !(flags & 4u)) {   // SPH = false: the scene holds triangles only (checked at upload), the sphere code is not compiled in
         double t;
         if (!tri_hit(g, ray, u, v, t)) return false;
         hp = ray.o + t * ray.d;
@@ -375,7 +376,7 @@ struct GlobalNodes {
 // nearest hit.  Control flow is "while-while": an inner loop walks nodes until THIS lane stands on a non-empty leaf, then the
 // leaf's triangles are tested; the 64 lanes of a wave therefore do their node steps together and their triangle tests together
 // instead of one lane's triangle loop stalling 63 lanes that want to take a node step.
-template <class Nodes>
+template <bool SPH, class Nodes>
 GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
     const int oct = dir_octant(ray);
@@ -408,7 +409,7 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
             double u, v;
             V3 hp;
             if (c) c->tri++;
-            if (!ent_hit(g, g.matflags, ray, u, v, hp)) return;
+            if (!ent_hit<SPH>(g, g.matflags, ray, u, v, hp)) return;
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 3];
                 if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) return;
@@ -421,10 +422,11 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
                 if (box_contains(lmin, lmax, hp)) term = true;
             }
         };
-        for (int32_t k = 0; k < cnt; k++) {
-            const double next_line = S.leaf_tris[first + (k + 1 < cnt ? k + 1 : k)].e1[1];   // pull the next record in while this one is tested
-            test(S.leaf_tris[first + k]);
-            GI_TOUCH(next_line);
+        for (int32_t k = 0; k < cnt; k += 2) {
+            const LeafTri g0 = S.leaf_tris[first + k];
+            const LeafTri g1 = S.leaf_tris[first + (k + 1 < cnt ? k + 1 : k)];
+            test(g0);
+            if (k + 1 < cnt) test(g1);
         }
         if (term) break;
     }
@@ -434,11 +436,11 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return trace_nodes(S, N, ray, rng, alpha_purpose, best, c);
+    return trace_nodes<true>(S, N, ray, rng, alpha_purpose, best, c);
 }
 
 // RayTracer::visible: any accepted hit with 0 < |hit-o|^2 < mt among the entities of every leaf the segment touches.
-template <class Nodes>
+template <bool SPH, class Nodes>
 GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
     const int oct = dir_octant(ray);
@@ -465,7 +467,7 @@ GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double 
             double u, v;
             V3 hp;
             if (c) c->tri++;
-            if (!ent_hit(g, g.matflags, ray, u, v, hp)) continue;
+            if (!ent_hit<SPH>(g, g.matflags, ray, u, v, hp)) continue;
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 3];
                 if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
@@ -480,7 +482,7 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return visible_nodes(S, N, ray, mt, rng, light_index, c);
+    return visible_nodes<true>(S, N, ray, mt, rng, light_index, c);
 }
 
 // ------------------------------------------------------------------------------------------------ photon gather
@@ -724,14 +726,14 @@ GI_HD void path_begin(PathRec& p, const Ray& ray, uint32_t sample)
     p.stream = sample; p.depth = 0; p.htri = -1; p.pad = 0;
 }
 // stage 1: RayTracer::trace for the current segment.  Miss: L += T*ambient and the path is finished (returns false).
-template <class Nodes>
+template <bool SPH, class Nodes>
 GI_HD bool stage_trace_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c)
 {
     Rng rng = rng_make(seed, p.stream);
     rng.depth = (uint32_t)p.depth;
     Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
     HitRec h;
-    if (!trace_nodes(S, N, ray, rng, P_TRACE_ALPHA, h, c)) {
+    if (!trace_nodes<SPH>(S, N, ray, rng, P_TRACE_ALPHA, h, c)) {
         V3 L = ld3(p.L) + ld3(p.T) * ld3(S.ambient);
         p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
         return false;
@@ -744,10 +746,10 @@ GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return stage_trace_nodes(S, N, p, seed, c);
+    return stage_trace_nodes<true>(S, N, p, seed, c);
 }
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
-template <class Nodes>
+template <bool SPH, class Nodes>
 GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c)
 {
     Rng rng = rng_make(seed, p.stream);
@@ -775,7 +777,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         double maxt = len2(lightDir);
         double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
         Ray sray = make_ray(so, lightDir);
-        if (visible_nodes(S, N, sray, maxt, rng, (uint32_t)li, c)) {
+        if (visible_nodes<SPH>(S, N, sray, maxt, rng, (uint32_t)li, c)) {
             double d = dot(norm, normalize(lpos - h.pos));
             if (d < 0) d = 0;
             // pow(d, 1/roughness): exact shortcuts for the two exponents every constant-texture scene uses (x^1 = x; x^inf for a
@@ -816,7 +818,7 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return stage_shade_nodes(S, N, p, seed, c);
+    return stage_shade_nodes<true>(S, N, p, seed, c);
 }
 // stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
 GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride)
