@@ -29,7 +29,7 @@ class SceneDesc(C.Structure):
     _fields_ = [("n_tri", C.c_int32), ("tri_pos", _dp), ("tri_nrm", _dp), ("tri_uv", _dp), ("tri_mat", _ip),
                 ("n_mat", C.c_int32), ("mats", _dp), ("n_light", C.c_int32), ("lights", _dp), ("ambient", C.c_double * 3),
                 ("n_node", C.c_int32), ("node_bbox", _dp), ("node_child", _ip), ("node_ent_off", _ip), ("node_ent_idx", _ip),
-                ("ent_kind", _ip)]
+                ("ent_kind", _ip), ("n_fog", C.c_int32), ("fog", _dp), ("fog_grid_off", _ip), ("fog_grid", _dp)]
 
 
 class PhotonMapDesc(C.Structure):
@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
-    "gih_add_light", "gih_add_sphere", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
+    "gih_add_light", "gih_add_sphere", "gih_add_height_fog", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
     "gih_counts", "gih_build_photon_map", "gih_get_photon_desc",
 ]
 
@@ -104,6 +104,7 @@ def lib():
     L.gih_add_triangles.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _ip]
     L.gih_add_light.argtypes = [vp, _dp, _dp, C.c_double]
     L.gih_add_sphere.argtypes = [vp, _dp, C.c_double, C.c_int32]
+    L.gih_add_height_fog.argtypes = [vp, _dp, _dp, C.c_int32, C.c_uint64]
     L.gih_set_ambient.argtypes = [vp, _dp]
     L.gih_get_settings.argtypes = [vp, C.POINTER(Settings)]
     L.gih_set_camera.argtypes = [vp, _dp, _dp]
@@ -176,6 +177,14 @@ class Scene:
         if self.L.gih_add_sphere(self.h, _p(_f64(centre)), float(radius), int(mat_idx)) != 0:
             raise GiError(self._err())
 
+    def add_height_fog(self, pos, size, col, density, scatter, noise_scale, grid=None, seed=DEFAULT_SEED):
+        """o->push_back(new HeightFog(...)) (include/sceneLoader.cpp:150-158).  grid=None fills the noise grid from the counter RNG
+        (the reference fills it with time-seeded drand())."""
+        par = _f64([*pos, *size, *col, density, scatter, noise_scale])
+        g = _f64(grid) if grid is not None else None
+        if self.L.gih_add_height_fog(self.h, _p(par), _p(g), 0 if g is None else len(g), C.c_uint64(seed)) != 0:
+            raise GiError(self._err())
+
     def add_light(self, pos, col, rad):
         self.L.gih_add_light(self.h, _p(_f64(pos)), _p(_f64(col)), float(rad))
 
@@ -217,6 +226,9 @@ class Scene:
             "node_child": _np_from(d.node_child, (d.n_node, 8), np.int32), "node_ent_off": _np_from(d.node_ent_off, (d.n_node + 1,), np.int32),
             "node_ent_idx": _np_from(d.node_ent_idx, (int(nref),), np.int32),
             "ent_kind": _np_from(d.ent_kind, (d.n_tri,), np.int32) if d.ent_kind else np.zeros(d.n_tri, np.int32),
+            "fog": _np_from(d.fog, (d.n_fog, 12), np.float64) if d.n_fog else np.zeros((0, 12)),
+            "fog_grid_off": _np_from(d.fog_grid_off, (d.n_fog + 1,), np.int32) if d.n_fog else np.zeros(1, np.int32),
+            "fog_grid": _np_from(d.fog_grid, (int(_np_from(d.fog_grid_off, (d.n_fog + 1,), np.int32)[-1]),), np.float64) if d.n_fog else np.zeros(0),
         }
 
     def build_photon_map(self, photons):

@@ -43,6 +43,9 @@ namespace gi {
 #define GI_MAX_DEPTH 64
 #define GI_PI 3.14159265358979323846
 #define GI_GATHER_K 32
+#define GI_RAYMARCH_STEPSIZE 0.04
+#define GI_FEAT_SPHERES 1   // template feature bits: code for entity kinds / media a scene does not contain is not compiled in
+#define GI_FEAT_FOG 2
 
 // ------------------------------------------------------------------------------------------------ device tables (HBM layout)
 struct NodeLink { int32_t hit, skip; };
@@ -80,6 +83,7 @@ struct alignas(128) PNode { // 128 B: photon octree node; the 8 children of a no
 };
 struct PRange { int32_t first, count; };   // photons are stored leaf by leaf in the reference's DFS order
 struct HaltonDim { uint32_t P, n, off; float scale; };
+struct FogD { double pos[3], size[3], col[3], d, sc, bmin[3], bmax[3]; int32_t grid_off, grid_n; };   // HeightFog, include/atmosphere.h:30-83
 
 struct Scene {
     const TNode* tnodes;      // [n_node]
@@ -93,10 +97,13 @@ struct Scene {
     const PRange* pranges;
     const double* ph_pos;     // [n_photon][3] leaf order
     const double* ph_dircol;  // [n_photon][6] leaf order
+    const FogD* fogs;
+    const double* fog_grid;
     const HaltonDim* hdims;   // [256]
     const uint16_t* htable;
     int32_t n_node, n_tri, n_light, n_pnode, n_photon;
     int32_t has_spheres;      // 0: triangles only
+    int32_t n_fog;
     double ambient[3];
 };
 
@@ -149,8 +156,9 @@ GI_HD uint64_t mix64(uint64_t z)
 enum {
     P_TRACE_ALPHA = 0, P_SHADOW_ALPHA = 1, P_LIGHT_X = 2, P_LIGHT_Y = 3, P_TYPE_OPACITY = 4, P_TYPE_FRESNEL = 5,
     P_RR = 6, P_FOG = 7, P_TRACE_GUARD = 8,
-    P_PH_DIR_U = 16, P_PH_DIR_V = 17, P_PH_SEC_U = 18, P_PH_SEC_V = 19, P_PH_TRACE0_ALPHA = 20
+    P_PH_DIR_U = 16, P_PH_DIR_V = 17, P_PH_SEC_U = 18, P_PH_SEC_V = 19, P_PH_TRACE0_ALPHA = 20, P_PH_FOG_U = 21, P_PH_FOG_V = 22
 };
+enum { P_FOG_CAMERA = 0, P_FOG_SHADOW = 1, P_FOG_PHOTON = 2 };   // `b` key of P_FOG draws (shadow: + 16 * light index); `a` = step
 #define GI_PHOTON_SEED_XOR 0x5048544f4e5eed00ull
 struct Rng {
     uint64_t hs;      // hash of (seed, stream)
@@ -305,6 +313,84 @@ GI_HD bool box_contains(const double* bmin, const double* bmax, V3 p)  // includ
 {
     return p.x >= bmin[0] && p.y >= bmin[1] && p.z >= bmin[2] && p.x < bmax[0] && p.y < bmax[1] && p.z < bmax[2];
 }
+// BoundingBox::intersect(ray, tmin, tmax, toutmin, toutmax), include/bbox.h:47-73
+GI_HD bool box_range(const double* bmin, const double* bmax, const Ray& r, double tmin, double tmax, double& t0o, double& t1o)
+{
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
+    for (int i = 0; i < 3; i++) {
+        double t0 = (bmin[i] - o[i]) * inv[i], t1 = (bmax[i] - o[i]) * inv[i];
+        if (inv[i] < 0.0) { double t = t0; t0 = t1; t1 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) return false;
+    }
+    t0o = tmin; t1o = tmax;
+    return true;
+}
+GI_HD double fast_pow(double a, double b)   // include/util.h:100-111
+{
+    union { double d; int32_t x[2]; } u;
+    u.d = a;
+    u.x[1] = (int32_t)(b * (u.x[1] - 1072632447) + 1072632447);
+    u.x[0] = 0;
+    return u.d;
+}
+// HeightFog::density, include/atmosphere.h:50-81 (nscale is 1 after construction; indices are computed in double as there)
+GI_HD double fog_density(const Scene& S, const FogD& f, V3 p)
+{
+    const double ymax = f.pos[1] + .5 * f.size[1];
+    const V3 rel = v3(p.x - f.bmin[0], p.y - f.bmin[1], p.z - f.bmin[2]);
+    const int rx = (int)rel.x, ry = (int)rel.y, rz = (int)rel.z;
+    const double dx = (rel.x - rx), dy = (rel.y - ry), dz = (rel.z - rz);
+    const double* G = S.fog_grid + f.grid_off;
+    const int last = f.grid_n - 1;
+#define GI_FOG_G(expr) G[((int)(expr)) < last ? (((int)(expr)) < 0 ? 0 : (int)(expr)) : last]
+    const double sx = f.size[0], sz = f.size[2];
+    double c00 = (1 - dx) * GI_FOG_G((rx * sx + ry) * sz + rz) + dx * GI_FOG_G(((rx + 1) * sx + ry) * sz + rz);
+    double c01 = (1 - dx) * GI_FOG_G((rx * sx + ry) * sz + rz + 1) + dx * GI_FOG_G(((rx + 1) * sx + ry) * sz + rz + 1);
+    double c10 = (1 - dx) * GI_FOG_G((rx * sx + (ry + 1)) * sz + rz) + dx * GI_FOG_G(((rx + 1) * sx + (ry + 1)) * sz + rz);
+    double c11 = (1 - dx) * GI_FOG_G((rx * sx + (ry + 1)) * sz + rz + 1) + dx * GI_FOG_G(((rx + 1) * sx + (ry + 1)) * sz + rz + 1);
+#undef GI_FOG_G
+    double c0 = c00 * (1 - dy) + c10 * dy;
+    double c1 = c01 * (1 - dy) + c11 * dy;
+    double noise = fast_pow((1 - dz) * c0 + dz * c1, 7);
+    return f.d * noise * fast_pow((ymax - p.y) / f.size[1], 2);
+}
+GI_HD double atmosphere_density(const Scene& S, V3 pos, V3& col)   // Octree::atmosphereDensity, include/octree.cpp:214-226
+{
+    double d = 0;
+    for (int i = 0; i < S.n_fog; i++) {
+        const FogD& f = S.fogs[i];
+        if (box_contains(f.bmin, f.bmax, pos)) { col = ld3(f.col); d += GI_RAYMARCH_STEPSIZE * fog_density(S, f, pos); }
+    }
+    return d;
+}
+GI_HD bool atmosphere_bounds(const Scene& S, const Ray& r, double& mint, double& maxt)   // Octree::atmosphereBounds, include/octree.cpp:229-251
+{
+    double mn = 0, mx = 0;
+    bool intersected = false;
+    for (int i = 0; i < S.n_fog; i++) {
+        double a, b;
+        if (box_range(S.fogs[i].bmin, S.fogs[i].bmax, r, mint, maxt, a, b)) { mn = a < mn ? a : mn; mx = b > mx ? b : mx; intersected = true; }
+    }
+    mint = mint > mn ? mint : mn;
+    maxt = maxt < mx ? maxt : mx;
+    return intersected;
+}
+// RayTracer::raymarch, include/raytracer.h:509-529: absorb with probability density*step per 0.04 step
+GI_HD bool raymarch(const Scene& S, const Ray& r, V3& hit, V3& col, double mint, double maxt, const Rng& rng, uint32_t which)
+{
+    double t = mint + GI_SHADOW_BIAS;
+    V3 current = r.o + mint * r.d;
+    uint32_t step = 0;
+    while (t < maxt) {
+        if (rng_draw(rng, P_FOG, step, which) < atmosphere_density(S, current, col)) { hit = current; return true; }
+        current = current + GI_RAYMARCH_STEPSIZE * r.d;
+        t += GI_RAYMARCH_STEPSIZE;
+        step++;
+    }
+    return false;
+}
 // child visiting order: the reference numbers children x = bit0, z = bit1, y = bit2 (include/octree.cpp:321-328)
 GI_HD int dir_octant(const Ray& r) { return (r.d.x < 0.0 ? 1 : 0) | (r.d.z < 0.0 ? 2 : 0) | (r.d.y < 0.0 ? 4 : 0); }
 
@@ -332,10 +418,10 @@ struct HitRec { V3 pos; double u, v; int32_t tri; };
 
 // Entity::intersect for the two kinds on this path: triangle (include/entities.h:443-490, barycentric u, v) and analytic sphere
 // (include/entities.h:60-101).  hp = hit point.
-template <bool SPH, class Tri>
+template <int FEAT, class Tri>
 GI_HD bool ent_hit(const Tri& g, uint32_t flags, const Ray& ray, double& u, double& v, V3& hp)
 {
-    if (!SPH || !(flags & 4u)) {   // SPH = false: the scene holds triangles only (checked at upload), the sphere code is not compiled in
+    if (!(FEAT & GI_FEAT_SPHERES) || !(flags & 4u)) {   // no sphere bit: the scene holds triangles only (checked at upload)
         double t;
         if (!tri_hit(g, ray, u, v, t)) return false;
         hp = ray.o + t * ray.d;
@@ -376,7 +462,7 @@ struct GlobalNodes {
 // nearest hit.  Control flow is "while-while": an inner loop walks nodes until THIS lane stands on a non-empty leaf, then the
 // leaf's triangles are tested; the 64 lanes of a wave therefore do their node steps together and their triangle tests together
 // instead of one lane's triangle loop stalling 63 lanes that want to take a node step.
-template <bool SPH, class Nodes>
+template <int FEAT, class Nodes>
 GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
     const int oct = dir_octant(ray);
@@ -409,7 +495,7 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
             double u, v;
             V3 hp;
             if (c) c->tri++;
-            if (!ent_hit<SPH>(g, g.matflags, ray, u, v, hp)) return;
+            if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return;
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 3];
                 if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) return;
@@ -436,11 +522,11 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return trace_nodes<true>(S, N, ray, rng, alpha_purpose, best, c);
+    return trace_nodes<3>(S, N, ray, rng, alpha_purpose, best, c);
 }
 
 // RayTracer::visible: any accepted hit with 0 < |hit-o|^2 < mt among the entities of every leaf the segment touches.
-template <bool SPH, class Nodes>
+template <int FEAT, class Nodes>
 GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
     const int oct = dir_octant(ray);
@@ -467,7 +553,7 @@ GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double 
             double u, v;
             V3 hp;
             if (c) c->tri++;
-            if (!ent_hit<SPH>(g, g.matflags, ray, u, v, hp)) continue;
+            if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) continue;
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 3];
                 if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
@@ -476,13 +562,20 @@ GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double 
             if ((ts < mt) && (ts > 0)) return false;
         }
     }
+    if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:308-316 (the reference bounds this march by the SQUARED length)
+        double tmin = 0, tmx = mt;
+        if (atmosphere_bounds(S, ray, tmin, tmx)) {
+            V3 fh, fc;
+            if (raymarch(S, ray, fh, fc, tmin, tmx, rng, P_FOG_SHADOW + 16u * light_index)) return false;
+        }
+    }
     return true;
 }
 GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return visible_nodes<true>(S, N, ray, mt, rng, light_index, c);
+    return visible_nodes<3>(S, N, ray, mt, rng, light_index, c);
 }
 
 // ------------------------------------------------------------------------------------------------ photon gather
@@ -726,14 +819,14 @@ GI_HD void path_begin(PathRec& p, const Ray& ray, uint32_t sample)
     p.stream = sample; p.depth = 0; p.htri = -1; p.pad = 0;
 }
 // stage 1: RayTracer::trace for the current segment.  Miss: L += T*ambient and the path is finished (returns false).
-template <bool SPH, class Nodes>
+template <int FEAT, class Nodes>
 GI_HD bool stage_trace_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c)
 {
     Rng rng = rng_make(seed, p.stream);
     rng.depth = (uint32_t)p.depth;
     Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
     HitRec h;
-    if (!trace_nodes<SPH>(S, N, ray, rng, P_TRACE_ALPHA, h, c)) {
+    if (!trace_nodes<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, h, c)) {
         V3 L = ld3(p.L) + ld3(p.T) * ld3(S.ambient);
         p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
         return false;
@@ -746,10 +839,10 @@ GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return stage_trace_nodes<true>(S, N, p, seed, c);
+    return stage_trace_nodes<3>(S, N, p, seed, c);
 }
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
-template <bool SPH, class Nodes>
+template <int FEAT, class Nodes>
 GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c)
 {
     Rng rng = rng_make(seed, p.stream);
@@ -767,6 +860,21 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     V3 refDir, f = v3(1, 1, 1), i = v3(0, 0, 0), contrib = ld3(p.contrib);
     double roughness, offset = GI_SHADOW_BIAS;
     secondary_ray(ray, m, norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
+    if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:209-228: the segment may end in the medium instead
+        double tmin = 0, tmx = length(h.pos - ray.o);
+        if (atmosphere_bounds(S, ray, tmin, tmx)) {
+            V3 fh, col;
+            if (raymarch(S, ray, fh, col, tmin, tmx, rng, P_FOG_CAMERA)) {
+                h.pos = fh;
+                p.hpos[0] = fh.x; p.hpos[1] = fh.y; p.hpos[2] = fh.z;   // the gather of this vertex uses the scatter point too
+                refDir = random_unit_vec(sx, sy);
+                f = 1.0 * col;
+                color = col;
+                contrib = col;
+                roughness = 1;
+            }
+        }
+    }
     for (int li = 0; li < S.n_light; li++) {
         const LightD& lt = S.lights[li];
         double ry = rng_draw(rng, P_LIGHT_Y | ((uint32_t)li << 8));
@@ -777,7 +885,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         double maxt = len2(lightDir);
         double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
         Ray sray = make_ray(so, lightDir);
-        if (visible_nodes<SPH>(S, N, sray, maxt, rng, (uint32_t)li, c)) {
+        if (visible_nodes<FEAT>(S, N, sray, maxt, rng, (uint32_t)li, c)) {
             double d = dot(norm, normalize(lpos - h.pos));
             if (d < 0) d = 0;
             // pow(d, 1/roughness): exact shortcuts for the two exponents every constant-texture scene uses (x^1 = x; x^inf for a
@@ -818,7 +926,7 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     GlobalNodes N;
     N.g = S.tnodes;
-    return stage_shade_nodes<true>(S, N, p, seed, c);
+    return stage_shade_nodes<3>(S, N, p, seed, c);
 }
 // stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
 GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride)
@@ -928,6 +1036,20 @@ GI_HD bool emit_photon(const Scene& S, int32_t i, int32_t li, int32_t count, int
                 double e13 = rng_draw(rng, P_PH_SEC_V);
                 double e5 = rng_draw(rng, P_PH_SEC_U);
                 secondary_ray(r, m, norm, fmod(e5 + 5 * i, 1.0), fmod(e13 + 13 * i, 1.0), refDir, f, roughness, contrib, offset, rng);
+                if (S.n_fog > 0) {   // include/raytracer.h:658-675
+                    double tmin = 0, tmx = length(hit - r.o);
+                    if (atmosphere_bounds(S, r, tmin, tmx)) {
+                        V3 ahit, fcol;
+                        if (raymarch(S, r, ahit, fcol, tmin, tmx, rng, P_FOG_PHOTON)) {
+                            hit = ahit;
+                            double g7 = rng_draw(rng, P_PH_FOG_V);
+                            double g13 = rng_draw(rng, P_PH_FOG_U);
+                            refDir = random_unit_vec(fmod(g13 + 13 * i, 1.0), fmod(g7 + 7 * i, 1.0));
+                            f = 1.0 * fcol;
+                            roughness = 1;
+                        }
+                    }
+                }
                 col = col * f;
                 r = make_ray(hit + offset * norm, refDir);
                 isCaustic = true;

@@ -146,6 +146,8 @@ struct gih_scene {
     std::vector<int32_t> ent_kind;   // 0 triangle, 1 sphere (centre = vertex 0, radius = vertex 1 x)
     std::vector<double> mats;     // 9 per material
     std::vector<double> lights;   // 11 per light
+    std::vector<double> fog, fog_grid;   // 12 per HeightFog; concatenated noise grids
+    std::vector<int32_t> fog_grid_off = std::vector<int32_t>(1, 0);
     gih_settings st;
     // octree
     bool tree_valid = false;
@@ -490,9 +492,9 @@ struct gih_scene {
                 if (mat < 0 || mat >= n_mats_here) { err = "sphere: material index out of range"; rc = -2; break; }
                 push_sphere(pos, rad, mat_base + mat);
             } else if (strcmp(word, "heightFog") == 0) {
-                err = std::string("keyword not supported by this build: ") + word;
-                rc = -2;
-                break;
+                double q[12] = {0};
+                fscanf(f, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf\n", &q[0], &q[1], &q[2], &q[3], &q[4], &q[5], &q[6], &q[7], &q[8], &q[9], &q[10], &q[11]);
+                if (add_height_fog(q, nullptr, 0, 0x9E3779B97F4A7C15ull) != 0) { rc = -2; break; }
             } else if (strcmp(word, "light") == 0) {
                 double p[3], c[3], rad = 0;
                 fscanf(f, "%lf %lf %lf %lf %lf %lf %lf\n", &p[0], &p[1], &p[2], &c[0], &c[1], &c[2], &rad);
@@ -511,6 +513,29 @@ struct gih_scene {
         }
         fclose(f);
         return rc;
+    }
+
+    // new HeightFog(pos, size, col, density, scatter, noiseScale), include/atmosphere.h:37-47: the noise grid has
+    // (sx+1)(sy+1)(sz+1) noiseScale^3 values; the reference draws them from time-seeded drand(), here they are given or come
+    // from the counter RNG (splitmix64 of seed and index)
+    int add_height_fog(const double* q, const double* grid, int n_grid, unsigned long long seed)
+    {
+        const int ns = (int)q[11];
+        const double want = (q[3] + 1) * (q[4] + 1) * (q[5] + 1) * std::pow((double)ns, 3);
+        int n = 0;
+        for (int i = 0; i < want; i++) n++;   // the constructor's loop: for (int i = 0; i < (double)N; i++)
+        if (n <= 0) { err = "heightFog: empty noise grid"; return -2; }
+        if (grid && n_grid != n) { err = "heightFog: noise grid size does not match (sx+1)(sy+1)(sz+1) scale^3"; return -2; }
+        fog.insert(fog.end(), q, q + 12);
+        for (int i = 0; i < n; i++) {
+            if (grid) { fog_grid.push_back(grid[i]); continue; }
+            unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)fog_grid.size() + 1);
+            z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull; z ^= z >> 27; z *= 0x94d049bb133111ebull; z ^= z >> 31;
+            fog_grid.push_back((double)(z >> 11) * (1.0 / 9007199254740992.0));
+        }
+        fog_grid_off.push_back((int32_t)fog_grid.size());
+        tree_valid = false;
+        return 0;
     }
 
     void add_light(const double* p, const double* c, double rad)
@@ -569,6 +594,12 @@ int gih_add_sphere(gih_scene* s, const double* centre3, double radius, int32_t m
     return 0;
 }
 
+int gih_add_height_fog(gih_scene* s, const double* params12, const double* grid, int32_t n_grid, uint64_t seed)
+{
+    if (!s || !params12) return -1;
+    return s->add_height_fog(params12, grid, n_grid, seed);
+}
+
 int gih_add_light(gih_scene* s, const double* pos3, const double* col3, double rad)
 {
     if (!s || !pos3 || !col3) return -1;
@@ -618,6 +649,8 @@ int gih_get_scene_desc(const gih_scene* s, gi_scene_desc* d)
     d->node_bbox = s->node_bbox.data(); d->node_child = s->node_child.data();
     d->node_ent_off = s->node_ent_off.data(); d->node_ent_idx = s->node_ent_idx.data();
     d->ent_kind = s->ent_kind.data();
+    d->n_fog = (int32_t)(s->fog.size() / 12);
+    d->fog = s->fog.data(); d->fog_grid_off = s->fog_grid_off.data(); d->fog_grid = s->fog_grid.data();
     return 0;
 }
 

@@ -21,7 +21,7 @@ void gih_scene_destroy(gih_scene*);
 const char* gih_last_error(const gih_scene*);
 
 /* replaces loadScene + loadOBJ (include/sceneLoader.cpp:12-185, include/meshLoader.cpp:18-99): same keyword set and the
- * same word-wise tokenising (keywords colorTex, mat, multiMat, mesh, sphere, box, light, photons, samples, ambient, camera);
+ * same word-wise tokenising (keywords colorTex, mat, multiMat, mesh, sphere, box, light, heightFog, photons, samples, ambient, camera);
  * vertices, normals and uvs are rounded to float as the reference's loader does.  A `mat` line
  * without its 5th number gets IOR 1.0 (the reference leaves it uninitialised).  Missing mesh files are skipped.
  * Returns 0, or -1 when the .scn itself cannot be opened.                                                            */
@@ -31,6 +31,9 @@ int gih_load_scn(gih_scene*, const char* path);
 int gih_add_material(gih_scene*, const double* mat9);                 /* returns the material index */
 int gih_add_triangles(gih_scene*, int32_t n, const double* pos, const double* nrm, const double* uv, const int32_t* mat_idx);
 int gih_add_sphere(gih_scene*, const double* centre3, double radius, int32_t mat_idx);   /* new sphere(pos, rad, mat) */
+/* new HeightFog(pos, size, col, density, scatter, noiseScale) (include/atmosphere.h:37-47): params12 as in gi_scene_desc::fog;
+ * grid = its (sx+1)(sy+1)(sz+1) scale^3 noise values, or NULL to fill them from the counter RNG with `seed`                  */
+int gih_add_height_fog(gih_scene*, const double* params12, const double* grid, int32_t n_grid, uint64_t seed);
 int gih_add_light(gih_scene*, const double* pos3, const double* col3, double rad);
 int gih_set_ambient(gih_scene*, const double* rgb3);
 

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec
 
 #define GI_TRACE_BLOCK 1024
 #define GI_SHADE_BLOCK 512
-template <bool SPH>
+template <int FEAT>
 __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf)
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
             slot = i < n_a ? q_a[i] : q_b[i - n_a];
             PathRec& p = pool[slot];
             if (p.depth > GI_MAX_DEPTH) fin = true;            // radiance() returns 0 past MAX_DEPTH
-            else { hit = stage_trace_nodes<SPH>(S, N, p, seed, nullptr); fin = !hit; }
+            else { hit = stage_trace_nodes<FEAT>(S, N, p, seed, nullptr); fin = !hit; }
         }
         const uint32_t at = wave_append(&ctl->n_shade, hit);
         if (hit) q_shade[at] = slot;
@@ -367,7 +367,7 @@ __device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& 
     return (oct << 24) | (m << 6) | db;
 }
 
-template <bool SPH>
+template <int FEAT>
 __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
 {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
         uint32_t slot = 0;
         if (valid) {
             slot = q_shade[i];
-            fl = stage_shade_nodes<SPH>(S, N, pool[slot], seed, nullptr);
+            fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr);
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
@@ -587,6 +587,8 @@ struct gi_ctx {
     DevBuf<TriShade> d_shade;
     DevBuf<Mat> d_mats;
     DevBuf<LightD> d_lights;
+    DevBuf<FogD> d_fogs;
+    DevBuf<double> d_fog_grid;
     DevBuf<PNode> d_pnodes;
     DevBuf<PRange> d_pranges;
     DevBuf<double> d_ph_pos, d_ph_dircol;
@@ -704,11 +706,14 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_shade.upload(H.shade));
     HIP_TRY(c, c->d_mats.upload(H.mats));
     HIP_TRY(c, c->d_lights.upload(H.lights));
+    HIP_TRY(c, c->d_fogs.upload(H.fogs));
+    HIP_TRY(c, c->d_fog_grid.upload(H.fog_grid));
     Scene& S = c->S;
     S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.leaf_tris = c->d_leaf_tris.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
     S.mats = c->d_mats.p; S.lights = c->d_lights.p;
     S.n_node = H.n_node; S.n_tri = H.n_tri; S.n_light = H.n_light;
     S.has_spheres = 0;
+    S.fogs = c->d_fogs.p; S.fog_grid = c->d_fog_grid.p; S.n_fog = H.n_fog();
     for (const TriGeom& g : H.tris) if (g.flags & 4u) S.has_spheres = 1;
     for (int k = 0; k < 3; k++) S.ambient[k] = H.ambient[k];
     // a new scene invalidates the photon map (RayTracer::setScene allocates a fresh PhotonMap, include/raytracer.h:38)
@@ -896,8 +901,8 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0, g_finish = 0;
     const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
     if (!g_trace) {
-        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<true>, lds_nodes, GI_TRACE_BLOCK);
-        g_shade = grid_for(c, (const void*)k_st_shade<true>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish);
+        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<3>, lds_nodes, GI_TRACE_BLOCK);
+        g_shade = grid_for(c, (const void*)k_st_shade<3>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish);
     }
     hipStream_t st = c->stream;
     PathRec* pool = c->d_pool.p;
@@ -944,10 +949,10 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             }
             HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
             uint32_t* qfree_out = q_free[ping];
-            const bool sph = c->S.has_spheres != 0;
-            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(sph ? k_st_trace<true> : k_st_trace<false>, dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+            const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0;
+            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(sph ? k_st_trace<GI_FEAT_SPHERES> : k_st_trace<0>, dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
                                q_shade, qfree_out, c->d_lbuf.p); stage_end(c);
-            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(sph ? k_st_shade<true> : k_st_shade<false>, dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
+            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(fog ? k_st_shade<3> : (sph ? k_st_shade<GI_FEAT_SPHERES> : k_st_shade<0>), dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
                                qfree_out, c->d_lbuf.p); stage_end(c);
             launches += 2;
             HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));

@@ -27,8 +27,11 @@ struct HostScene {
     std::vector<TriShade> shade;
     std::vector<Mat> mats;
     std::vector<LightD> lights;
+    std::vector<FogD> fogs;
+    std::vector<double> fog_grid;
     int32_t n_node = 0, n_tri = 0, n_light = 0;
     double ambient[3] = {0, 0, 0};
+    int32_t n_fog() const { return (fogs.size() == 1 && fogs[0].grid_n == 0) ? 0 : (int32_t)fogs.size(); }
 };
 struct HostPhotons {
     std::vector<PNode> nodes;
@@ -220,6 +223,23 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         for (int k = 0; k < 3; k++) { H.lights[i].pos[k] = l[k]; H.lights[i].col[k] = l[3 + k]; H.lights[i].dir[k] = l[7 + k]; }
         H.lights[i].rad = l[6]; H.lights[i].angle = l[10];
     }
+    H.fogs.clear(); H.fog_grid.clear();
+    if (d->n_fog < 0 || (d->n_fog > 0 && (!d->fog || !d->fog_grid_off || !d->fog_grid))) { err = "scene: bad atmosphere tables"; return false; }
+    for (int i = 0; i < d->n_fog; i++) {
+        const double* q = d->fog + (size_t)i * 12;
+        FogD f;
+        for (int k = 0; k < 3; k++) {
+            f.pos[k] = q[k]; f.size[k] = q[3 + k]; f.col[k] = q[6 + k];
+            f.bmin[k] = q[k] - .5 * q[3 + k]; f.bmax[k] = q[k] + .5 * q[3 + k];   // AtmosphereEntity ctor, include/atmosphere.h:14
+        }
+        f.d = q[9]; f.sc = q[10];
+        f.grid_off = d->fog_grid_off[i];
+        f.grid_n = d->fog_grid_off[i + 1] - d->fog_grid_off[i];
+        if (f.grid_n <= 0 || f.grid_off < 0) { err = "scene: empty fog noise grid"; return false; }
+        H.fogs.push_back(f);
+    }
+    if (d->n_fog > 0) H.fog_grid.assign(d->fog_grid, d->fog_grid + d->fog_grid_off[d->n_fog]);
+    if (H.fogs.empty()) { FogD z; memset(&z, 0, sizeof z); H.fogs.push_back(z); H.fog_grid.push_back(0); }   // non-null tables; n_fog stays 0
     H.n_node = d->n_node; H.n_tri = d->n_tri; H.n_light = d->n_light;
     for (int k = 0; k < 3; k++) H.ambient[k] = d->ambient[k];
     return true;

@@ -48,6 +48,12 @@ typedef struct gi_scene_desc {
     /* entity kinds (include/entities.h): NULL = all triangles; else [n_tri] with 0 = triangle, 1 = analytic sphere
      * (include/entities.h:51-142) whose centre is tri_pos[i][0] and radius tri_pos[i][1].x (normals / uvs unused)          */
     const int32_t* ent_kind;
+    /* atmosphere entities (Octree::at, include/octree.h:43): HeightFog (include/atmosphere.h:30-83).  fog [n_fog][12] = pos, size,
+     * colour, density, scatter, noise scale; the noise grid of entity i is fog_grid[fog_grid_off[i] .. fog_grid_off[i+1])         */
+    int32_t n_fog;
+    const double* fog;
+    const int32_t* fog_grid_off;
+    const double* fog_grid;
 } gi_scene_desc;
 
 /* Photon set + linearised PhotonMap (include/photonMap.h:13-49, include/photon.h:5-15). */

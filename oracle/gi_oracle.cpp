@@ -31,6 +31,7 @@ const double EPSILON = 0.00001;
 const double SHADOW_BIAS = 0.0001;
 const int MIN_DEPTH = 2;
 const int MAX_DEPTH = 64;
+const double RAYMARCH_STEPSIZE = 0.04;
 const double PI = 3.14159265358979323846;  // glibc M_PI (util.h's fallback #define is not taken)
 
 // ----------------------------------------------------------------------------- vec3 with glm operand order
@@ -73,9 +74,12 @@ inline double counter_rand(uint64_t seed, uint32_t stream, uint32_t depth, uint3
 }
 // purposes of the counter RNG contract (low byte; light index in bits 8..)
 enum {
+    P_FOG_CAMERA = 0, P_FOG_SHADOW = 1, P_FOG_PHOTON = 2,   // `b` key of P_FOG draws: which march of the vertex (shadow: + light index)
+};
+enum {
     P_TRACE_ALPHA = 0, P_SHADOW_ALPHA = 1, P_LIGHT_X = 2, P_LIGHT_Y = 3, P_TYPE_OPACITY = 4, P_TYPE_FRESNEL = 5,
     P_RR = 6, P_FOG = 7, P_TRACE_GUARD = 8,
-    P_PH_DIR_U = 16, P_PH_DIR_V = 17, P_PH_SEC_U = 18, P_PH_SEC_V = 19, P_PH_TRACE0_ALPHA = 20
+    P_PH_DIR_U = 16, P_PH_DIR_V = 17, P_PH_SEC_U = 18, P_PH_SEC_V = 19, P_PH_TRACE0_ALPHA = 20, P_PH_FOG_U = 21, P_PH_FOG_V = 22
 };
 const uint64_t PHOTON_SEED_XOR = 0x5048544f4e5eed00ull;
 
@@ -427,6 +431,7 @@ struct Entity {
     bool smooth;    // all three vertex normals non-zero, include/entities.h:478
 };
 struct Light { V3 pos, col; double rad; V3 dir; double angle; };
+struct Fog { V3 pos, size, col; double d, sc; int nscale; std::vector<double> grid; };  // HeightFog, include/atmosphere.h:30-83
 
 struct Hit { V3 pos, norm; V2 uv; };
 
@@ -532,6 +537,7 @@ struct gio_ctx {
     std::vector<Entity> ents;
     std::vector<Material> mats;
     std::vector<Light> lights;
+    std::vector<Fog> fogs;
     V3 ambient = {0, 0, 0};
     V3 cam_pos = {10, 5, 0}, cam_up = {0, 1, 0}, cam_fwd = {-1, 0, 0};
     double sensorDiag = 0.035 * 240 * 2, focalDist = 0.04 * 240;
@@ -651,6 +657,59 @@ struct gio_ctx {
         }
     }
 
+    // ---- atmosphere (HeightFog), include/atmosphere.h:50-81, include/octree.cpp:214-251, include/raytracer.h:509-529
+    Box fog_box(const Fog& f) const { return Box{f.pos - .5 * f.size, f.pos + .5 * f.size}; }
+    double fog_density(const Fog& f, V3 p) const
+    {
+        const Box bb = fog_box(f);
+        const double nscale = (double)f.nscale;
+        double ymax = f.pos.y + .5 * f.size.y;
+        V3 rel = nscale * (p - bb.min);
+        double dx = nscale * (rel.x - (int)rel.x), dy = nscale * (rel.y - (int)rel.y), dz = nscale * (rel.z - (int)rel.z);
+        auto g = [&](double idx) { size_t i = (size_t)idx; return f.grid[i < f.grid.size() ? i : f.grid.size() - 1]; };   // the reference reads out of bounds there
+        const int rx = (int)rel.x, ry = (int)rel.y, rz = (int)rel.z;
+        double c00 = (1 - dx) * g((rx * nscale * f.size.x + ry) * nscale * f.size.z + rz) + dx * g(((rx + 1) * nscale * f.size.x + ry) * nscale * f.size.z + rz);
+        double c01 = (1 - dx) * g((rx * nscale * f.size.x + ry) * nscale * f.size.z + rz + 1) + dx * g(((rx + 1) * nscale * f.size.x + ry) * nscale * f.size.z + rz + 1);
+        double c10 = (1 - dx) * g((rx * nscale * f.size.x + (ry + 1)) * nscale * f.size.z + rz) + dx * g(((rx + 1) * nscale * f.size.x + (ry + 1)) * nscale * f.size.z + rz);
+        double c11 = (1 - dx) * g((rx * nscale * f.size.x + (ry + 1)) * nscale * f.size.z + rz + 1) + dx * g(((rx + 1) * nscale * f.size.x + (ry + 1)) * nscale * f.size.z + rz + 1);
+        double c0 = c00 * (1 - dy) + c10 * dy;
+        double c1 = c01 * (1 - dy) + c11 * dy;
+        double noise = fast_pow((1 - dz) * c0 + dz * c1, 7);
+        return f.d * noise * fast_pow((ymax - p.y) / f.size.y, 2);
+    }
+    double atmosphere_density(V3 pos, V3& col) const   // Octree::atmosphereDensity, include/octree.cpp:214-226
+    {
+        double d = 0;
+        for (const Fog& f : fogs)
+            if (fog_box(f).contains(pos)) { col = f.col; d += RAYMARCH_STEPSIZE * fog_density(f, pos); }
+        return d;
+    }
+    bool atmosphere_bounds(const Ray& r, double& mint, double& maxt) const   // Octree::atmosphereBounds, include/octree.cpp:229-251
+    {
+        double mn = 0, mx = 0;
+        bool intersected = false;
+        for (const Fog& f : fogs) {
+            double tmpmin = 0, tmpmax = 0;
+            if (fog_box(f).intersect(r, mint, maxt, tmpmin, tmpmax)) { mn = std::min(mn, tmpmin); mx = std::max(mx, tmpmax); intersected = true; }
+        }
+        mint = std::max(mint, mn);
+        maxt = std::min(maxt, mx);
+        return intersected;
+    }
+    bool raymarch(const Ray& r, V3& hit, V3& col, double mint, double maxt, Rng& rng, uint32_t which) const   // include/raytracer.h:509-529
+    {
+        double t = mint + SHADOW_BIAS;
+        V3 current = r.origin + mint * r.dir;
+        uint32_t step = 0;
+        while (t < maxt) {
+            if (rng.draw(P_FOG, step, which) < atmosphere_density(current, col)) { hit = current; return true; }
+            current = current + RAYMARCH_STEPSIZE * r.dir;
+            t += RAYMARCH_STEPSIZE;
+            step++;
+        }
+        return false;
+    }
+
     double mat_alpha(const Material& m) const { return m.opacity * 1.0; }  // Material::getAlpha with a constant texture, material.h:90-93
 
     // RayTracer::trace, include/raytracer.h:382-478.  alpha_purpose selects the counter-RNG purpose of the alpha draws.
@@ -708,6 +767,11 @@ struct gio_ctx {
             ++k;
         }
         if (hit) return false;
+        double tmin = 0, tmax = mt;   // the reference passes the SQUARED length here (include/raytracer.h:308-309)
+        if (!fogs.empty() && atmosphere_bounds(ray, tmin, tmax)) {
+            V3 fh, fc;
+            if (raymarch(ray, fh, fc, tmin, tmax, rng, P_FOG_SHADOW + 16 * light_index)) return false;
+        }
         return true;
     }
 
@@ -893,6 +957,20 @@ struct gio_ctx {
             double roughness = m.roughness;
             V3 f = v3(1, 1, 1);
             secondary_ray(ray, m, mh.norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
+            {   // include/raytracer.h:209-228
+                double tmin = 0, tmax = length(mh.pos - ray.origin);
+                if (!fogs.empty() && atmosphere_bounds(ray, tmin, tmax)) {
+                    V3 fh, col;
+                    if (raymarch(ray, fh, col, tmin, tmax, rng, P_FOG_CAMERA)) {
+                        mh.pos = fh;
+                        refDir = random_unit_vec(sx, sy);
+                        f = 1.0 * col;
+                        color = col;
+                        contrib = col;
+                        roughness = 1;
+                    }
+                }
+            }
             uint32_t li = 0;
             for (const Light& light : lights) {
                 bool shadow = false;
@@ -1014,6 +1092,21 @@ struct gio_ctx {
                             double e13 = rng.draw(P_PH_SEC_V);
                             double e5 = rng.draw(P_PH_SEC_U);
                             secondary_ray(r, m, h.norm, std::fmod(e5 + 5 * i, 1), std::fmod(e13 + 13 * i, 1), refDir, f, roughness, contrib, offset, rng);
+                            {   // include/raytracer.h:658-675
+                                double tmin = 0, tmax = length(h.pos - r.origin);
+                                if (!fogs.empty() && atmosphere_bounds(r, tmin, tmax)) {
+                                    V3 ahit, color;
+                                    if (raymarch(r, ahit, color, tmin, tmax, rng, P_FOG_PHOTON)) {
+                                        h.pos = ahit;
+                                        // randomUnitVec(fmod(drand()+13*i,1), fmod(drand()+7*i,1)): g++ draws the second argument first
+                                        double g7 = rng.draw(P_PH_FOG_V);
+                                        double g13 = rng.draw(P_PH_FOG_U);
+                                        refDir = random_unit_vec(std::fmod(g13 + 13 * i, 1), std::fmod(g7 + 7 * i, 1));
+                                        f = 1.0 * color;
+                                        roughness = 1;
+                                    }
+                                }
+                            }
                             col = col * f;
                             r.origin = h.pos + offset * h.norm;
                             r.set_dir(refDir);
@@ -1074,6 +1167,27 @@ int gio_set_scene(gio_ctx* c, int n_ent, const int32_t* ent_kind, const double* 
     if (ambient3) c->ambient = v3(ambient3[0], ambient3[1], ambient3[2]);
     c->octree_valid = false;
     c->pmap_valid = false;
+    return 0;
+}
+
+int gio_set_fog(gio_ctx* c, int n, const double* params12, const int32_t* grid_off, const double* grid)
+{
+    c->fogs.resize(n);
+    for (int i = 0; i < n; i++) {
+        const double* q = params12 + (size_t)i * 12;
+        Fog& f = c->fogs[i];
+        f.pos = v3(q[0], q[1], q[2]); f.size = v3(q[3], q[4], q[5]); f.col = v3(q[6], q[7], q[8]);
+        f.d = q[9]; f.sc = q[10]; f.nscale = 1;   // the constructor forces nscale = 1 after sizing the grid (include/atmosphere.h:46)
+        f.grid.assign(grid + grid_off[i], grid + grid_off[i + 1]);
+        if (f.grid.empty()) return -1;
+    }
+    return 0;
+}
+int gio_chain_discard(gio_ctx* c, int64_t n)
+{
+    Rng r; r.state = c->chain_state;
+    for (int64_t i = 0; i < n; i++) r.chain_next();
+    c->chain_state = r.state;
     return 0;
 }
 

@@ -34,6 +34,11 @@ void gio_destroy(gio_ctx*);
 int gio_set_scene(gio_ctx*, int n_ent, const int32_t* ent_kind, const double* pos, const double* nrm, const double* uv,
                   const int32_t* mat_idx, int n_mat, const double* mats, int n_light, const double* lights,
                   const double* ambient3);
+/* HeightFog entities (include/atmosphere.h:30-83): params [n][12] = pos, size, col, density, scatter, noise scale; the noise grids
+ * (the reference fills them with drand() in the constructor) are passed explicitly: grid_off [n+1] into grid.               */
+int gio_set_fog(gio_ctx*, int n, const double* params12, const int32_t* grid_off, const double* grid);
+/* GIO_RNG_CHAIN: skip draws the reference made outside the render path (the HeightFog constructor's noise grid)              */
+int gio_chain_discard(gio_ctx*, int64_t n);
 /* camera: pos(3) up(3) forward(3) sensorDiag focalDist  (include/camera.h) */
 int gio_set_camera(gio_ctx*, const double* cam11);
 

@@ -35,6 +35,9 @@ CHAINS = {
     # all four spheres, one of them half transparent (stochastic alpha test: exact only on the pinned chain)
     "chain_spheres_lin": (f"{ROOT}/scenes/spheres/spheres.scn", 40, 30, 4, 1500, "lin"),
     "chain_spheres_run": (f"{ROOT}/scenes/spheres/spheres.scn", 40, 30, 4, 1500, "run"),
+    # HeightFog: ray-marched medium on camera segments, shadow rays and photon paths (scenes/fog/fog.scn, our scene file)
+    "chain_fog_lin": (f"{ROOT}/scenes/fog/fog.scn", 40, 30, 4, 1500, "lin"),
+    "chain_fog_run": (f"{ROOT}/scenes/fog/fog.scn", 40, 30, 4, 1500, "run"),
 }
 
 

@@ -274,6 +274,20 @@ static void dump_scene_tables(Loaded& L, const std::string& out)
     for (Light* l : L.scene->lights) li.insert(li.end(), {l->pos.x, l->pos.y, l->pos.z, l->col.x, l->col.y, l->col.z, l->rad, l->dir.x, l->dir.y, l->dir.z, l->angle});
     save_f64(out + "/lights.npy", li, {L.scene->lights.size(), 11});
 
+    {   // atmosphere entities (HeightFog): parameters + the noise grid its constructor filled with drand()
+        std::vector<double> fp, fg;
+        std::vector<int32_t> fo = {0};
+        for (AtmosphereEntity* a : L.scene->at) {
+            HeightFog* hf = dynamic_cast<HeightFog*>(a);
+            if (!hf) continue;
+            fp.insert(fp.end(), {hf->pos.x, hf->pos.y, hf->pos.z, hf->s.x, hf->s.y, hf->s.z, hf->col.x, hf->col.y, hf->col.z, hf->d, hf->sc, (double)hf->nscale});
+            fg.insert(fg.end(), hf->noiseGrid.begin(), hf->noiseGrid.end());
+            fo.push_back((int32_t)fg.size());
+        }
+        save_f64(out + "/fog.npy", fp, {fp.size() / 12, 12});
+        save_f64(out + "/fog_grid.npy", fg, {fg.size()});
+        save_i32(out + "/fog_grid_off.npy", fo, {fo.size()});
+    }
     std::vector<double> misc = {L.rt.ambient.x, L.rt.ambient.y, L.rt.ambient.z, (double)L.rt.min_samples, (double)L.rt.max_samples, L.rt.noise_thresh,
                                 (double)L.rt.photons, (double)L.rt.photon_depth,
                                 L.rt._camera.pos.x, L.rt._camera.pos.y, L.rt._camera.pos.z,

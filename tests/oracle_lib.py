@@ -61,6 +61,8 @@ def lib():
         L.gio_primary_ray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dp]
         L.gio_set_scene.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip, C.c_int, c_dp, C.c_int, c_dp, c_dp]
         L.gio_set_camera.argtypes = [C.c_void_p, c_dp]
+        L.gio_set_fog.argtypes = [C.c_void_p, C.c_int, c_dp, c_ip, c_dp]
+        L.gio_chain_discard.argtypes = [C.c_void_p, C.c_int64]
         L.gio_build_octree.argtypes = [C.c_void_p]
         L.gio_chain_seed.argtypes = [C.c_void_p, C.c_uint64]
         L.gio_octree_counts.argtypes = [C.c_void_p, c_ip, c_ip]
@@ -129,6 +131,16 @@ class Oracle:
         assert r == 0
         return self
 
+    def set_fog(self, params, grid_off, grid):
+        params = np.ascontiguousarray(params, np.float64).reshape(-1, 12)
+        grid_off = np.ascontiguousarray(grid_off, np.int32); grid = np.ascontiguousarray(grid, np.float64)
+        assert self.L.gio_set_fog(self.h, len(params), _ptr(params, c_dp), _ptr(grid_off, c_ip), _ptr(grid, c_dp)) == 0
+        return self
+
+    def chain_discard(self, n):
+        self.L.gio_chain_discard(self.h, int(n))
+        return self
+
     def set_camera(self, pos, up, forward, sensor_diag=16.8, focal_dist=9.6):
         cam = np.array(list(pos) + list(up) + list(forward) + [sensor_diag, focal_dist], np.float64)
         self.L.gio_set_camera(self.h, _ptr(cam, c_dp))
@@ -142,6 +154,8 @@ class Oracle:
                     fx["settings"][0:3], kind=fx["ent_kind"])
         s = fx["settings"]
         o.set_camera(s[8:11], s[11:14], s[14:17], s[20], s[21])
+        if "fog" in fx and len(fx["fog"]):
+            o.set_fog(fx["fog"], fx["fog_grid_off"], fx["fog_grid"])
         return o
 
     def chain_seed(self, seed):

@@ -72,3 +72,17 @@ def test_render_with_stochastic_alpha_and_glass_matches_oracle():
     rt = el.EmulRayTracer().setScene(scene)
     rmse, img, ref = pc.check_render(rt, scene, 40, 30, 6, 1500)
     assert rmse < 1e-12 and img.mean() > 0.01
+
+
+def test_height_fog_render_and_emission_match_oracle():
+    """scenes/fog/fog.scn: HeightFog ray-marched on camera segments, shadow rays and photon paths (include/raytracer.h:209-228,
+    308-316, 658-675); every 0.04 step draws from the keyed RNG."""
+    scene = pc.load_scene("fog")
+    assert scene.desc().n_fog == 1
+    rt = el.EmulRayTracer().setScene(scene)
+    pc.check_emission(rt, scene, 800)
+    rmse, img, ref = pc.check_render(rt, scene, 32, 24, 4, 800)
+    assert rmse < 1e-12
+    # the medium changes the picture: the same scene without fog is different
+    t = scene.tables()
+    assert len(t["fog_grid"]) == 6 * 2 * 6 * 64

@@ -132,6 +132,17 @@ def test_render_with_stochastic_alpha_and_glass_matches_oracle(mode):
     assert rmse < 1e-9 and img.mean() > 0.01
 
 
+@pytest.mark.parametrize("mode", ["wavefront", "rounds", "megakernel"])
+def test_height_fog_render_and_emission_match_oracle(mode):
+    """scenes/fog/fog.scn: HeightFog ray-marched on camera segments, shadow rays and photon paths."""
+    scene = pc.load_scene("fog")
+    rt = gi.RayTracer(0).setScene(scene)
+    rt.set_render_mode(mode)
+    pc.check_emission(rt, scene, 2000)
+    rmse, img, ref = pc.check_render(rt, scene, 80, 60, 8, 2000)
+    assert rmse < 1e-9 and img.mean() > 0.005
+
+
 def test_no_photon_map_gather_is_zero():
     scene = pc.load_scene("caustics")
     rt = gi.RayTracer(0).setScene(scene)

@@ -64,6 +64,8 @@ def test_bad_inputs_fail_loudly(tmp_path):
         s.desc()                                   # octree not built
     with pytest.raises(gi.GiError):
         s.add_triangles(np.zeros((1, 3, 3)), mat_idx=[3])   # no such material
+    with pytest.raises(gi.GiError):
+        s.add_height_fog((0, 0, 0), (1, 1, 1), (1, 1, 1), 1, .5, 2, grid=np.zeros(5))   # grid must have (sx+1)(sy+1)(sz+1) scale^3 values
     scn = tmp_path / "t.scn"
     scn.write_text("imTex a.png 1 1\n")
     with pytest.raises(gi.GiError):

@@ -131,13 +131,15 @@ def test_photon_octree_and_gather_identical(scene):
 
 # ------------------------------------------------------------------ whole frames on the pinned RNG chain (a-1, a-2, a-10, f1)
 @pytest.mark.parametrize("name", ["chain_test_scene_lin", "chain_caustics_lin", "chain_cornell_lin", "chain_caustics_run", "chain_cornell_run",
-                                  "chain_spheres_lin", "chain_spheres_run"])
+                                  "chain_spheres_lin", "chain_spheres_run", "chain_fog_lin", "chain_fog_run"])
 def test_whole_frame_matches_reference_bit_for_bit(golden, name):
     """The reference's frame (its own RayTracer::run for *_run; radiance() per sample for *_lin) on a pinned time() and
     one OpenMP thread, including tracePhotons and the photon-map build, reproduced by the oracle's chain RNG mode."""
     fx = golden(name)
     W, H, spp, nph, T, isrun = [int(v) for v in fx["chain_meta"]]
     o = ol.Oracle.from_fixture(fx).build_octree().chain_seed(T)
+    if "fog_grid" in fx:
+        o.chain_discard(len(fx["fog_grid"]))      # the HeightFog constructor drew its noise grid from the chain at load time
     if nph > 0 and len(fx["lights"]):
         n, _ = o.emit_photons(nph, 5, ol.RNG_CHAIN)
         assert n == len(fx["chain_photons_leaforder"])
