@@ -417,6 +417,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
 
 // the last stragglers of a chunk (paths bouncing inside closed specular geometry up to MAX_DEPTH): one lane runs one path to
 // its end instead of one nearly empty pass per remaining depth
+template <int FEAT>
 __global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                         const uint32_t* q_cont, uint32_t n_in, double* lbuf)
 {
@@ -424,9 +425,11 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, 
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
         const uint32_t slot = q_cont[i];
         PathRec p = pool[slot];
+        GlobalNodes N;
+        N.g = S.tnodes;
         while (p.depth <= GI_MAX_DEPTH) {
-            if (!stage_trace(S, p, seed, nullptr)) break;
-            const int fl = stage_shade(S, p, seed, nullptr);
+            if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) break;
+            const int fl = stage_shade_nodes<FEAT>(S, N, p, seed, nullptr);
             if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_BLOCK, nullptr);
             if (!(fl & ST_CONTINUE)) break;
         }
@@ -902,7 +905,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
     if (!g_trace) {
         g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<3>, lds_nodes, GI_TRACE_BLOCK);
-        g_shade = grid_for(c, (const void*)k_st_shade<3>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish);
+        g_shade = grid_for(c, (const void*)k_st_shade<3>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<3>);
     }
     hipStream_t st = c->stream;
     PathRec* pool = c->d_pool.p;
@@ -943,7 +946,8 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             uint32_t* qcont_out = q_cont[ping];
             const uint32_t* qcont_in = q_cont[ping ^ 1];
             if (next >= sample_end && n_new == 0 && n_cont <= c->finish_threshold) {
-                stage_begin(c, STG_FINISH); hipLaunchKernelGGL(k_st_finish, dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, qcont_in, n_cont, c->d_lbuf.p); stage_end(c);
+                const bool sphf = c->S.has_spheres != 0, fogf = c->S.n_fog > 0;
+                stage_begin(c, STG_FINISH); hipLaunchKernelGGL(fogf ? k_st_finish<3> : (sphf ? k_st_finish<GI_FEAT_SPHERES> : k_st_finish<0>), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, qcont_in, n_cont, c->d_lbuf.p); stage_end(c);
                 launches++;
                 break;
             }

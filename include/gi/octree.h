@@ -7,6 +7,7 @@
 #include <stdexcept>
 #include <vector>
 #include "../../gi_raytracer_amd/csrc/gi_host.h"
+#include "atmosphere.h"
 #include "entities.h"
 #include "light.h"
 
@@ -18,10 +19,12 @@ class Octree {
     Octree& operator=(const Octree&) = delete;
 
     std::vector<Light*> lights;
+    std::vector<AtmosphereEntity*> at;
     bool valid = false;
 
     void push_back(Entity* object) { _entities.push_back(object); valid = false; }
     void push_back(Light* light) { lights.push_back(light); valid = false; }
+    void push_back(AtmosphereEntity* entity) { at.push_back(entity); valid = false; }
 
     // Octree::rebuild, include/octree.cpp:53-119
     void rebuild()
@@ -55,6 +58,12 @@ class Octree {
             for (Light* l : lights) {
                 const double p[3] = {l->pos.x, l->pos.y, l->pos.z}, c[3] = {l->col.x, l->col.y, l->col.z};
                 gih_add_light(s, p, c, l->rad);
+            }
+            for (AtmosphereEntity* a : at) {
+                HeightFog* hf = dynamic_cast<HeightFog*>(a);
+                if (!hf) { gih_scene_destroy(fresh); throw std::runtime_error("Octree::rebuild: only HeightFog atmosphere entities are on the GPU path"); }
+                const double q[12] = {hf->pos.x, hf->pos.y, hf->pos.z, hf->s.x, hf->s.y, hf->s.z, hf->col.x, hf->col.y, hf->col.z, hf->d, hf->sc, (double)hf->nscale};
+                if (gih_add_height_fog(s, q, nullptr, 0, 0x9E3779B97F4A7C15ull) != 0) { std::string e = gih_last_error(s); gih_scene_destroy(fresh); throw std::runtime_error(e); }
             }
             gih_scene_destroy(_h);
             _h = fresh;

@@ -26,6 +26,7 @@ int main(int argc, char** argv)
     quad->push_back(new triangle(vertex(gi::dvec3(0, 0, 0)), vertex(gi::dvec3(1, 0, 0)), vertex(gi::dvec3(0, 0, 1)), mat));
     quad->push_back(new triangle(vertex(gi::dvec3(1, 0, 0)), vertex(gi::dvec3(1, 0, 1)), vertex(gi::dvec3(0, 0, 1)), mat));
     quad->push_back(new sphere(gi::dvec3(0.5, 0.3, 0.5), 0.3, mat));
+    quad->push_back(new HeightFog(gi::dvec3(0.5, 0.5, 0.5), gi::dvec3(1, 1, 1), gi::dvec3(1, 1, 1), 2, .5, 2));
     quad->push_back(new Light(gi::dvec3(0, 5, 0), gi::dvec3(0, 0, 0), gi::dvec3(4, 4, 4), .05));
     quad->rebuild();
     printf("quad valid %d\n", (int)quad->valid);
