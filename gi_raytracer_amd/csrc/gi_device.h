@@ -664,6 +664,50 @@ GI_HD void for_each_candidate(const Scene& S, const PRange* ranges, int n_ranges
         }
     }
 }
+// The selection as three small steps, so that the per-lane walk below and the wave-cooperative kernel (candidates staged in LDS,
+// gi_kernels.hip) run the very same arithmetic:  g_key per candidate (pass 1), g_acc per candidate (pass 2), g_end.
+struct GatherAcc {
+    V3 pos, dir;
+    Heap h;
+    float tau;
+    int ncand;
+    V3 s_lt, s_eq;
+    int c_lt, c_eq;
+    double r_eq;
+};
+GI_HD void g_begin(GatherAcc& a, V3 pos, V3 dir, float* heap_mem, int heap_stride, int ncand)
+{
+    a.pos = pos; a.dir = dir;
+    a.h.hp = heap_mem; a.h.stride = heap_stride; a.h.n = 0;
+    a.tau = 0; a.ncand = ncand;
+    a.s_lt = v3(0, 0, 0); a.s_eq = v3(0, 0, 0);
+    a.c_lt = 0; a.c_eq = 0; a.r_eq = 0;
+}
+GI_HD void g_key(GatherAcc& a, V3 pp)
+{
+    float key = (float)len2(pp - a.pos);
+    if (a.h.n < GI_GATHER_K) { heap_push(a.h, key); a.tau = a.h.hp[0]; }
+    else if (key < a.tau) { heap_replace_root(a.h, key); a.tau = a.h.hp[0]; }
+}
+GI_HD void g_acc(GatherAcc& a, V3 pp, const double* dc)
+{
+    double d2 = len2(pp - a.pos);
+    float key = (float)d2;
+    if (key <= a.tau) {
+        V3 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), a.dir);
+        if (key < a.tau) { a.s_lt = a.s_lt + contrib; a.c_lt++; }
+        else { a.s_eq = a.s_eq + contrib; a.c_eq++; a.r_eq = d2 > a.r_eq ? d2 : a.r_eq; }
+    }
+}
+// false: float keys tie across rank 32 -- the caller has to resolve the tie group with exact distances (pass 3)
+GI_HD bool g_end(const GatherAcc& a, V3& res)
+{
+    const int K = a.ncand < GI_GATHER_K ? a.ncand : GI_GATHER_K;
+    const int need = K - a.c_lt;  // >= 1: the heap root itself is a candidate with key == tau
+    if (a.c_eq > need) return false;
+    res = (a.s_lt + a.s_eq) / (GI_PI * a.r_eq);
+    return true;
+}
 GI_HD V3 gather_in_leaf(const Scene& S, int32_t node, V3 pos, V3 dir, float* heap_mem, int heap_stride, int* n_cand_out, Counters* c)
 {
     V3 res = v3(0, 0, 0);
@@ -678,59 +722,37 @@ GI_HD V3 gather_in_leaf(const Scene& S, int32_t node, V3 pos, V3 dir, float* hea
     if (n_cand_out) *n_cand_out = ncand;
     if (c) c->pcand += (unsigned long long)ncand;
     if (ncand == 0) return res;
-    // pass 1
-    Heap h;
-    h.hp = heap_mem; h.stride = heap_stride; h.n = 0;
-    float tau = 0;
-    for_each_candidate(S, ranges, n_ranges, [&](int32_t, V3 pp) {
-        float key = (float)len2(pp - pos);
-        if (h.n < GI_GATHER_K) { heap_push(h, key); tau = h.hp[0]; }
-        else if (key < tau) { heap_replace_root(h, key); tau = h.hp[0]; }
-    });
+    GatherAcc a;
+    g_begin(a, pos, dir, heap_mem, heap_stride, ncand);
+    for_each_candidate(S, ranges, n_ranges, [&](int32_t, V3 pp) { g_key(a, pp); });                                       // pass 1
+    for_each_candidate(S, ranges, n_ranges, [&](int32_t idx, V3 pp) { g_acc(a, pp, S.ph_dircol + (size_t)idx * 6); });    // pass 2
+    if (g_end(a, res)) return res;
+    // pass 3 (rare): the `need` nearest of the tie group by exact distance, one extraction per scan
     const int K = ncand < GI_GATHER_K ? ncand : GI_GATHER_K;
-    // pass 2
-    V3 s_lt = v3(0, 0, 0), s_eq = v3(0, 0, 0);
-    int c_lt = 0, c_eq = 0;
-    double r_eq = 0;
-    for_each_candidate(S, ranges, n_ranges, [&](int32_t idx, V3 pp) {
-        double d2 = len2(pp - pos);
-        float key = (float)d2;
-        if (key <= tau) {
-            const double* dc = S.ph_dircol + (size_t)idx * 6;
-            V3 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
-            if (key < tau) { s_lt = s_lt + contrib; c_lt++; }
-            else { s_eq = s_eq + contrib; c_eq++; r_eq = d2 > r_eq ? d2 : r_eq; }
-        }
-    });
-    const int need = K - c_lt;  // >= 1: the heap root itself is a candidate with key == tau
-    double r2;
-    if (c_eq <= need) { res = s_lt + s_eq; r2 = r_eq; }
-    else {
-        // pass 3 (rare): the `need` nearest of the tie group by exact distance, one extraction per scan
-        res = s_lt;
-        double last = -1.0;
-        for (int j = 0; j < need; j++) {
-            double best = INFINITY;
-            V3 bc = v3(0, 0, 0);
-            for (int r = 0; r < n_ranges; r++) {
-                const PRange rg = ranges[r];
-                const double* pp = S.ph_pos + (size_t)rg.first * 3;
-                for (int32_t k = 0; k < rg.count; k++, pp += 3) {
-                    double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
-                    if ((float)d2 == tau && d2 > last && d2 < best) {
-                        const double* dc = S.ph_dircol + (size_t)(rg.first + k) * 6;
-                        best = d2;
-                        bc = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
-                    }
+    const int need = K - a.c_lt;
+    const float tau = a.tau;
+    res = a.s_lt;
+    double last = -1.0;
+    for (int j = 0; j < need; j++) {
+        double best = INFINITY;
+        V3 bc = v3(0, 0, 0);
+        for (int r = 0; r < n_ranges; r++) {
+            const PRange rg = ranges[r];
+            const double* pp = S.ph_pos + (size_t)rg.first * 3;
+            for (int32_t k = 0; k < rg.count; k++, pp += 3) {
+                double d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
+                if ((float)d2 == tau && d2 > last && d2 < best) {
+                    const double* dc = S.ph_dircol + (size_t)(rg.first + k) * 6;
+                    best = d2;
+                    bc = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
                 }
             }
-            if (best == INFINITY) break;   // exact duplicates exhausted the group
-            res = res + bc;
-            last = best;
         }
-        r2 = last;
+        if (best == INFINITY) break;   // exact duplicates exhausted the group
+        res = res + bc;
+        last = best;
     }
-    res = res / (GI_PI * r2);
+    res = res / (GI_PI * last);
     return res;
 }
 GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride, int* n_cand_out, Counters* c)

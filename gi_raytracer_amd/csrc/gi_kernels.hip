@@ -405,13 +405,70 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gkeys(Scene S, const PathRec* p
         vals[i] = slot;
     }
 }
+// Queries arrive sorted by leaf, and a leaf typically serves thousands of queries per pass, so most waves hold 64 queries of ONE
+// leaf: such a wave copies the leaf's candidate photons into LDS once (64 at a time, one photon per lane, coalesced) and every lane
+// scans them from there -- a broadcast LDS read per candidate instead of an L2 round trip per lane.  Waves that straddle a leaf
+// boundary take the per-lane walk.  Both run g_key / g_acc / g_end, i.e. the same arithmetic in the same order.
+#define GI_GCHUNK 64
 __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in)
 {
     __shared__ float heap[GI_GATHER_K * GI_BLOCK];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
-        const uint32_t leaf = keys[i];
-        if (leaf >= (uint32_t)S.n_pnode) continue;   // no leaf contains the point: the caustic term is 0
-        stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap + threadIdx.x, GI_BLOCK);
+    __shared__ double cand[GI_BLOCK / 64][GI_GCHUNK][9];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_round = (n_in + 63u) & ~63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_round; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < n_in;
+        const uint32_t leaf = valid ? keys[i] : 0xffffffffu;
+        const uint32_t leaf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
+        const bool has_leaf = valid && leaf < (uint32_t)S.n_pnode;
+        const bool uniform = __ballot(valid && leaf != leaf0) == 0ull && leaf0 < (uint32_t)S.n_pnode;
+        if (!uniform) {
+            if (has_leaf) stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap + threadIdx.x, GI_BLOCK);
+            continue;
+        }
+        const PNode& lf = S.pnodes[leaf0];
+        const int ncand = lf.nb_photons;
+        if (ncand == 0) continue;
+        const PRange* ranges = S.pranges + lf.nb_off;
+        const int n_ranges = lf.nb_cnt;
+        GatherAcc a;
+        PathRec* p = valid ? &pool[vals[i]] : nullptr;
+        if (valid) g_begin(a, ld3(p->hpos), ld3(p->gdir), heap + threadIdx.x, GI_BLOCK, ncand);
+        for (int pass = 0; pass < 2; pass++) {
+            for (int r = 0; r < n_ranges; r++) {
+                const PRange rg = ranges[r];
+                for (int32_t c0 = 0; c0 < rg.count; c0 += GI_GCHUNK) {
+                    const int32_t m = min((int32_t)GI_GCHUNK, rg.count - c0);
+                    __builtin_amdgcn_wave_barrier();
+                    if ((int32_t)lane < m) {
+                        const size_t ph = (size_t)(rg.first + c0 + (int32_t)lane);
+                        const double* pp = S.ph_pos + ph * 3;
+                        cand[wave][lane][0] = pp[0]; cand[wave][lane][1] = pp[1]; cand[wave][lane][2] = pp[2];
+                        if (pass == 1) {
+                            const double* dc = S.ph_dircol + ph * 6;
+                            for (int k = 0; k < 6; k++) cand[wave][lane][3 + k] = dc[k];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (valid) {
+                        for (int32_t k = 0; k < m; k++) {
+                            const double* q = cand[wave][k];
+                            if (pass == 0) g_key(a, v3(q[0], q[1], q[2]));
+                            else g_acc(a, v3(q[0], q[1], q[2]), q + 3);
+                        }
+                    }
+                }
+            }
+        }
+        if (valid) {
+            V3 caustic;
+            if (!g_end(a, caustic)) caustic = gather_in_leaf(S, (int32_t)leaf0, a.pos, a.dir, heap + threadIdx.x, GI_BLOCK, nullptr, nullptr);   // float-key tie: exact pass
+            V3 L = ld3(p->L) + ld3(p->gcoef) * caustic;
+            p->L[0] = L.x; p->L[1] = L.y; p->L[2] = L.z;
+        }
     }
 }
 
