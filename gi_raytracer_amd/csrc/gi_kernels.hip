@@ -472,26 +472,43 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
     }
 }
 
-// the last stragglers of a chunk (paths bouncing inside closed specular geometry up to MAX_DEPTH): one lane runs one path to
-// its end instead of one nearly empty pass per remaining depth
+// the last stragglers of a chunk (paths bouncing between specular surfaces up to MAX_DEPTH), finished without one nearly
+// empty pass per remaining depth.  A wave's bounce costs what its most divergent lanes cost (one depth-65 path alone in a
+// wave: ~150 us per bounce; 15 unrelated ones sharing a wave: ~730 us), and the tail of a frame is one dependent chain of
+// such bounces, so the finisher runs in stages: stage k gives each wave `lanes` paths (lanes 0..lanes-1, the rest idle),
+// advances them at most `max_bounces` vertices, and hands the survivors to stage k+1, which spreads them thinner.  The
+// survivor count stays on the device (n_in_dev): no host round trip between stages.
 template <int FEAT>
 __global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
-                                                        const uint32_t* q_cont, uint32_t n_in, double* lbuf)
+                                                        const uint32_t* q_in, const unsigned int* n_in_dev, uint32_t n_in_host, int lanes, int max_bounces,
+                                                        uint32_t* q_out, unsigned int* n_out, double* lbuf)
 {
     __shared__ float heap[GI_GATHER_K * GI_BLOCK];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = q_cont[i];
+    const uint32_t n_in = n_in_dev ? *n_in_dev : n_in_host;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    if (lanes <= 0) lanes = (int)min(64u, max(1u, (n_in + n_waves - 1) / n_waves));   // spread the paths evenly over the resident waves
+    if (lane >= (uint32_t)lanes) return;
+    for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
+        const uint32_t slot = q_in[i];
         PathRec p = pool[slot];
         GlobalNodes N;
         N.g = S.tnodes;
-        while (p.depth <= GI_MAX_DEPTH) {
-            if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) break;
+        bool alive = true;
+        for (int b = 0;;) {
+            if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; break; }
             const int fl = stage_shade_nodes<FEAT>(S, N, p, seed, nullptr);
             if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_BLOCK, nullptr);
-            if (!(fl & ST_CONTINUE)) break;
+            if (!(fl & ST_CONTINUE)) { alive = false; break; }
+            if (++b >= max_bounces) break;
         }
-        const unsigned long long id = slot_sample[slot] - sample0;
-        lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
+        if (alive) {
+            pool[slot] = p;
+            q_out[atomicAdd(n_out, 1u)] = slot;
+        } else {
+            const unsigned long long id = slot_sample[slot] - sample0;
+            lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
+        }
     }
 }
 
@@ -680,6 +697,10 @@ struct gi_ctx {
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
     size_t pool_slots_max = (size_t)1 << 30;    // upper bound on paths in flight; the actual pool is also bounded by free HBM (render_streaming)
     uint32_t finish_threshold = 1u << 17;
+    // finisher stages {paths per wave (0: spread evenly over the resident waves), max vertices}; the last stage runs to MAX_DEPTH.
+    // Measured on the default frame (tools/stripe_probe.py): one full-wave stage 60 ms, this plan 51 ms; on 1/8 of the rows 40 -> 30 ms.
+    std::vector<std::pair<int, int>> finish_plan = {{0, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 4}, {0, 8}, {0, GI_MAX_DEPTH + 1}};
+    DevBuf<unsigned int> d_fin_cnt;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0;
     int last_launches = 0;
@@ -727,6 +748,18 @@ int gi_create(gi_ctx** out, int device_ordinal)
     }
     c->S.hdims = c->d_hdims.p;
     c->S.htable = c->d_htable.p;
+    if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
+    if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."
+        std::vector<std::pair<int, int>> plan;
+        for (const char* q = e; *q;) {
+            int l = 0, b = 0, used = 0;
+            if (sscanf(q, "%d:%d%n", &l, &b, &used) != 2 || l < 0 || l > 64 || b < 1) { plan.clear(); break; }
+            plan.push_back({l, b});
+            q += used;
+            if (*q == ',') q++;
+        }
+        if (!plan.empty()) c->finish_plan = plan;
+    }
     *out = c;
     return GI_OK;
 }
@@ -1004,8 +1037,21 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             const uint32_t* qcont_in = q_cont[ping ^ 1];
             if (next >= sample_end && n_new == 0 && n_cont <= c->finish_threshold) {
                 const bool sphf = c->S.has_spheres != 0, fogf = c->S.n_fog > 0;
-                stage_begin(c, STG_FINISH); hipLaunchKernelGGL(fogf ? k_st_finish<3> : (sphf ? k_st_finish<GI_FEAT_SPHERES> : k_st_finish<0>), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, qcont_in, n_cont, c->d_lbuf.p); stage_end(c);
-                launches++;
+                if (c->d_fin_cnt.n < 16) HIP_TRY(c, c->d_fin_cnt.alloc(16));
+                HIP_TRY(c, hipMemsetAsync(c->d_fin_cnt.p, 0, 16 * sizeof(unsigned int), st));
+                const uint32_t* fq_in = qcont_in;
+                uint32_t* fq_out = qcont_out;
+                const size_t n_stage = std::min<size_t>(c->finish_plan.size(), 15);
+                for (size_t k = 0; k < n_stage; k++) {
+                    const int lanes = c->finish_plan[k].first, vertices = k + 1 == n_stage ? GI_MAX_DEPTH + 1 : c->finish_plan[k].second;
+                    const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
+                    stage_begin(c, STG_FINISH);
+                    hipLaunchKernelGGL(fogf ? k_st_finish<3> : (sphf ? k_st_finish<GI_FEAT_SPHERES> : k_st_finish<0>), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
+                                       fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, c->d_lbuf.p);
+                    stage_end(c);
+                    launches++;
+                    uint32_t* t = const_cast<uint32_t*>(fq_in); fq_in = fq_out; fq_out = t;   // both are this chunk's continuation queues
+                }
                 break;
             }
             HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
@@ -1094,6 +1140,7 @@ int gi_last_render_ms(gi_ctx* c, float* ms, int32_t* n_launches)
     for (size_t k = 0; k + 1 < c->ev_used + 1 && k / 2 < c->ev_stage.size() && k + 1 < c->ev_pool.size() && k < c->ev_used; k += 2) {
         float t = 0;
         if (hipEventElapsedTime(&t, c->ev_pool[k], c->ev_pool[k + 1]) == hipSuccess) c->stage_ms[c->ev_stage[k / 2]] += t;
+        if (getenv("GI_DEBUG_STAGES")) fprintf(stderr, "[stage] %d %.3f ms\n", c->ev_stage[k / 2], t);
     }
     if (ms) *ms = c->last_ms;
     if (n_launches) *n_launches = c->last_launches;

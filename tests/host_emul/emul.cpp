@@ -99,6 +99,31 @@ int emul_radiance(Emul* e, int n, const double* rays, const uint32_t* stream, ui
     }
     return 0;
 }
+// per-path work profile of one frame: for every path that shades more than `min_shaded` vertices, its 8 counters (profiling aid)
+int emul_deep_paths(Emul* e, const gi_render_params* p, int min_shaded, int cap, int64_t* out8, int32_t* n_out, double* rays6, uint32_t* streams)
+{
+    Frame F;
+    if (!make_frame(p, F, e->err)) return GI_E_INVALID;
+    float heap[GI_GATHER_K];
+    int n = 0;
+    for (int y = 0; y < F.local_rows; y++)
+        for (int x = 0; x < F.w; x++)
+            for (int s = 0; s < F.max_samples; s++) {
+                uint32_t idx;
+                Ray ray = primary_ray(e->S, F, s, x, global_row(F, y), idx);
+                Counters c;
+                memset(&c, 0, sizeof c);
+                radiance_path(e->S, ray, idx, F.seed, heap, 1, &c);
+                if ((int)c.shaded > min_shaded && n < cap) {
+                    memcpy(out8 + (size_t)n * 8, &c, sizeof c);
+                    if (rays6) { double* r = rays6 + (size_t)n * 6; r[0] = ray.o.x; r[1] = ray.o.y; r[2] = ray.o.z; r[3] = ray.d.x; r[4] = ray.d.y; r[5] = ray.d.z; }
+                    if (streams) streams[n] = idx;
+                    n++;
+                }
+            }
+    *n_out = n;
+    return 0;
+}
 int emul_render(Emul* e, const gi_render_params* p, double* out, int32_t* out_spp, int64_t* counters8)
 {
     Frame F;

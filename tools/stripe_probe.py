@@ -1,0 +1,21 @@
+"""Time one rank's share of the default frame for several world sizes on ONE GPU (predicts strong scaling)."""
+import sys, json
+import numpy as np
+import torch
+import gi_raytracer_amd as gi
+scene = gi.Scene.load("scenes/caustics/caustics.scn").rebuild()
+rt = gi.RayTracer(0).setScene(scene)
+rt.tracePhotons(200000)
+w, h, spp = 1920, 1080, 256
+for world in [int(a) for a in sys.argv[1:]] or (1, 2, 4, 8):
+    sh = 16 if world > 1 else h
+    p = rt.params(w, h, stripe_h=sh, rank=0, world=world, min_samples=spp, max_samples=spp)
+    rows = rt.local_rows(p)
+    buf = torch.empty((rows, w, 3), dtype=torch.float32, device="cuda:0")
+    for it in range(2):
+        rt.run_device(p, buf.data_ptr())
+        torch.cuda.synchronize()
+    ms = rt.last_render_ms()[0]
+    st = rt.last_stage_ms()
+    base = 974.0
+    print(world, rows, round(ms, 1), "eff", round(base / (ms * world), 3), {k: round(v, 1) for k, v in st.items()}, flush=True)
