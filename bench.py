@@ -40,6 +40,28 @@ def algorithmic_bytes_per_sample(counters, n_samples, spp):
     return 32 * v + 36 * t + 96 * hh + 36 * p + 12.0 / spp, mix
 
 
+def measured_traffic(scene, w, h, spp, photons, world, mode):
+    """HBM bytes of one frame from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), as committed under
+    profiles/ for exactly this workload; bench.py cannot sit under the profiler itself.  FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md (HBM section) prescribes for gfx950."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        k = d.get("workload_key")
+        if k == {"scene": scene, "frame": [w, h], "spp": spp, "photons": photons, "n_gpus": world, "mode": mode}:
+            best = (path, d)
+    if best is None:
+        return None
+    path, d = best
+    return {"traffic": 2.0 * d["frame_fetch_bytes_uncorrected"] + d["frame_write_bytes"], "traffic_unit": "bytes per frame (one pass of the pipeline)",
+            "traffic_source": os.path.relpath(path, ROOT) + ": 2 x FETCH_SIZE + WRITE_SIZE"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,14 +194,14 @@ def main():
             rmse = float(np.sqrt(((img[rows_sel].astype(np.float64) - lin[rows_sel]) ** 2).mean()))
             out["config"]["rmse_vs_oracle_on_cpu_rows"] = rmse
         if bytes_per_sample is None:
-            # per-sample mix measured by the oracle on this workload (profiles/r01_notes.md); used when the CPU leg is skipped
+            # per-sample mix measured by the oracle on this workload (profiles/*_bench.json: per_sample_mix); used when the CPU leg is skipped
             bytes_per_sample, mix = 32 * 99.1 + 36 * 56.1 + 96 * 0.90 + 36 * 71.9 + 12.0 / spp, None
         local_samples = rows * w * spp
         stages = {k: float(np.mean([s[k] for s in stage_ms])) for k in stage_ms[0]} if stage_ms else {}
         pipeline_ms = sum(stages.values()) if sum(stages.values()) > 0 else kernel_ms_avg   # megakernel mode: one launch
         achieved = bytes_per_sample * local_samples / (pipeline_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                           "traffic": None,
+                           "traffic": None,   # filled below from the committed PMC measurement of this very workload, if there is one
                            "kernel": "streaming wavefront pipeline of one frame: k_st_regen, k_st_trace, k_st_shade, k_st_gkeys + 2 radix sorts, k_st_gather, k_st_finish, k_st_accum"
                                      if args.mode == "wavefront" else args.mode,
                            "kernel_ms": pipeline_ms, "frame_ms_event_to_event": kernel_ms_avg, "stage_ms": stages,
@@ -193,6 +215,9 @@ def main():
                 a = stage_bytes[dom] * local_samples / (stages[dom] * 1e-3) / 1e9
                 out["roofline"]["dominant"] = {"kernel": "k_st_" + dom, "ms_per_frame": stages[dom], "algorithmic_bytes_per_sample": stage_bytes[dom],
                                                "achieved": a, "frac": a / HBM_PEAK_GBS}
+        tr = measured_traffic(args.scene, w, h, spp, args.photons, world, args.mode)
+        if tr is not None:
+            out["roofline"].update(tr)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
