@@ -55,7 +55,7 @@ _LIB = None
 # every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
-    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
+    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_light", "gih_add_sphere", "gih_add_height_fog", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
@@ -83,6 +83,7 @@ def lib():
     L.gi_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int, vp, vp]
     L.gi_render_host.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int, vp, vp]
     L.gi_set_render_mode.argtypes = [vp, C.c_int]
+    L.gi_set_wide_nodes.argtypes = [vp, C.c_int]
     L.gi_set_pool_slots.argtypes = [vp, C.c_int64]
     L.gi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), _ip]
     L.gi_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -347,6 +348,13 @@ class RayTracer:
     def set_render_mode(self, mode):
         """'wavefront' (default) or 'megakernel': two schedules of the same per-path arithmetic."""
         self._check(self.L.gi_set_render_mode(self.h, {"wavefront": 0, "megakernel": 1, "rounds": 2}[mode]), "set_render_mode")
+
+    def set_wide_nodes(self, on):
+        """Octree walk over wide records (default) or one box test per node record; returns whether the wide walk is in use."""
+        rc = self.L.gi_set_wide_nodes(self.h, 1 if on else 0)
+        if rc < 0:
+            self._check(rc, "set_wide_nodes")
+        return rc == 1
 
     def set_pool_slots(self, slots):
         self._check(self.L.gi_set_pool_slots(self.h, int(slots)), "set_pool_slots")

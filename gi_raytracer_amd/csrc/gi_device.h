@@ -59,6 +59,22 @@ struct alignas(128) TNode { // 128 B = one L2 line: a scene-octree node, stored 
     NodeLink link[8];       // per direction octant: next node when the box is hit (inner nodes) / when the sub-tree is left;
                             // following them visits the children of every node front to back for that octant; END = n_node
 };
+// Wide node: one record per INNER node holding what the box tests of all its (up to 8) children need.  Octree::Node::partition
+// (include/octree.cpp:318-328) builds the children's boxes from five planes per axis: children on the low side span [min, mid],
+// children on the high side [min + .5 d, mid + .5 d], except child 7 which spans [mid, max] (mid = mix(min, max, .5); the three
+// forms of "the middle" and of "the far side" differ in the last bit).  The record keeps those planes exactly as the children's
+// boxes hold them (checked bit for bit when the scene is laid out; a tree of another shape keeps the per-node walk), so one record
+// and 36 multiply-subtracts replace eight records and 96.  pl[axis] = {min, mid, lo2, hi2, max, mid}: the pairs (0,1), (2,3),
+// (5,4) are the low-side, high-side and child-7 intervals, and a ray that runs backwards along the axis reads every pair in the
+// opposite order (entry plane first) by xor-ing 8 into the byte offset -- the swap of include/bbox.h:52-57 costs no instruction.
+struct alignas(32) WNode {  // 224 B
+    double pl[3][6];        // x, y, z
+    int32_t ca[8], cb[8];   // child slot c (x = bit 0, z = bit 1, y = bit 2): cb < 0: inner, wide record ca; cb > 0: leaf, its references
+                            // are leaf_tris[ca .. ca + cb); cb == 0: no such child (or an empty leaf)
+    int32_t parent;         // wide record of the parent, -1 at the root
+    uint32_t exists;        // bit c: child slot c is an inner node or a non-empty leaf
+    int32_t pad[2];
+};
 struct TriGeom {            // 80 B: what a ray-triangle test needs
     double p0[3], e1[3], e2[3];
     int32_t mat;
@@ -87,6 +103,8 @@ struct FogD { double pos[3], size[3], col[3], d, sc, bmin[3], bmax[3]; int32_t g
 
 struct Scene {
     const TNode* tnodes;      // [n_node]
+    const WNode* wnodes;      // [n_wnode] inner nodes, breadth first; null when the tree is not made of exact octants
+    const int32_t* wleaf_id;  // [n_wnode][8] canonical node index of a leaf child (RNG key of the alpha test)
     const int32_t* leaf_refs;
     const LeafTri* leaf_tris; // [n_refs], parallel to leaf_refs
     const TriGeom* tris;
@@ -102,6 +120,7 @@ struct Scene {
     const HaltonDim* hdims;   // [256]
     const uint16_t* htable;
     int32_t n_node, n_tri, n_light, n_pnode, n_photon;
+    int32_t n_wnode;
     int32_t has_spheres;      // 0: triangles only
     int32_t n_fog;
     double ambient[3];
@@ -445,6 +464,7 @@ GI_HD bool ent_hit(const Tri& g, uint32_t flags, const Ray& ray, double& u, doub
 // Where node records come from: plain global memory here; gi_kernels.hip adds a source that serves the first nodes from LDS.
 struct NodeView { double bmin[3], bmax[3]; int32_t first_ref, n_ref, hit, skip; };
 struct GlobalNodes {
+    static constexpr bool kWide = false;
     const TNode* g;
     GI_HDM void fetch(int32_t i, int oct, NodeView& v) const
     {
@@ -457,6 +477,189 @@ struct GlobalNodes {
     GI_HDM int32_t leaf_id(int32_t i) const { return g[i].leaf_id; }
 };
 
+// ------------------------------------------------------------------------------------------------ wide-node walk
+// The same walk as trace_nodes / visible_nodes below -- children of every node in the order k ^ a, every child's box tested with
+// the reference's slab arithmetic, leaves met in the same order -- but a node's children are tested together from the WNode of
+// their parent.  BoundingBox::intersect updates tmin upwards and tmax downwards axis by axis and leaves at the first
+// tmax <= tmin (include/bbox.h:47-73); both are monotone, so it returns false exactly when the final tmax <= tmin, and
+// `t0 > tmin ? t0 : tmin` is maxNum (a NaN from 0 * inf is ignored), which is what fmax / v_max_f64 compute.
+struct WRay { int off[3]; int a; };   // per axis: 8 when the ray runs backwards along it (invDir < 0), else 0; a = direction octant
+GI_HD WRay wray_make(const Ray& r)
+{
+    WRay w;
+    w.off[0] = r.inv.x < 0.0 ? 8 : 0; w.off[1] = r.inv.y < 0.0 ? 8 : 0; w.off[2] = r.inv.z < 0.0 ? 8 : 0;
+    w.a = (r.d.x < 0.0 ? 1 : 0) | (r.d.z < 0.0 ? 2 : 0) | (r.d.y < 0.0 ? 4 : 0);
+    return w;
+}
+// bit k of the result: the k-th child in this ray's front-to-back order (slot k ^ a) exists and its box is hit in (tmin0, tmax0)
+GI_HD uint32_t wide_hits(const WNode* w, const Ray& r, const WRay& wr, double tmin0, double tmax0)
+{
+    const char* b = reinterpret_cast<const char*>(w);
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
+    double n[3][3], f[3][3];   // [axis][low side, high side, child 7]: entry and exit parameter
+    for (int ax = 0; ax < 3; ax++) {
+        const int A = ax * 48, x = wr.off[ax], y = x ^ 8;
+        n[ax][0] = (*reinterpret_cast<const double*>(b + A + x) - o[ax]) * inv[ax];
+        f[ax][0] = (*reinterpret_cast<const double*>(b + A + y) - o[ax]) * inv[ax];
+        n[ax][1] = (*reinterpret_cast<const double*>(b + A + 16 + x) - o[ax]) * inv[ax];
+        f[ax][1] = (*reinterpret_cast<const double*>(b + A + 16 + y) - o[ax]) * inv[ax];
+        n[ax][2] = (*reinterpret_cast<const double*>(b + A + 32 + y) - o[ax]) * inv[ax];
+        f[ax][2] = (*reinterpret_cast<const double*>(b + A + 32 + x) - o[ax]) * inv[ax];
+    }
+    const double nx[2] = {fmax(n[0][0], tmin0), fmax(n[0][1], tmin0)}, fx[2] = {fmin(f[0][0], tmax0), fmin(f[0][1], tmax0)};
+    uint32_t m = 0;
+    for (int bz = 0; bz < 2; bz++)
+        for (int bx = 0; bx < 2; bx++) {
+            const double nA = fmax(nx[bx], n[2][bz]), fA = fmin(fx[bx], f[2][bz]);
+            for (int by = 0; by < 2; by++) {
+                const double t0 = fmax(nA, n[1][by]), t1 = fmin(fA, f[1][by]);
+                if (t1 > t0) m |= 1u << (bx | (bz << 1) | (by << 2));
+            }
+        }
+    {
+        const double t0 = fmax(fmax(fmax(n[0][2], tmin0), n[1][2]), n[2][2]), t1 = fmin(fmin(fmin(f[0][2], tmax0), f[1][2]), f[2][2]);
+        m = (m & 0x7fu) | (t1 > t0 ? 0x80u : 0u);
+    }
+    m &= w->exists;
+    if (wr.a & 1) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    if (wr.a & 2) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (wr.a & 4) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    return m;
+}
+GI_HD void wide_leaf_box(const WNode* w, int slot, double* lmin, double* lmax)   // the box of child `slot` as partition() built it
+{
+    const int bit[3] = {slot & 1, (slot >> 2) & 1, (slot >> 1) & 1};   // x, y, z
+    for (int ax = 0; ax < 3; ax++) {
+        if (slot == 7) { lmin[ax] = w->pl[ax][5]; lmax[ax] = w->pl[ax][4]; }
+        else { lmin[ax] = w->pl[ax][bit[ax] * 2]; lmax[ax] = w->pl[ax][bit[ax] * 2 + 1]; }
+    }
+}
+struct GlobalWide {
+    static constexpr bool kWide = true;
+    const WNode* g;
+    template <class F> GI_HDM auto with(int32_t i, F&& f) const { return f(g + i); }
+};
+// walk state: the node, the children of it still to visit (bit k = k-th in order), and the same masks of its ancestors, one
+// byte per level, in a 128-bit shift register (16 levels; deeper trees keep the per-node walk)
+struct WWalk {
+    int32_t node;
+    uint32_t m;
+    unsigned long long lo, hi;
+};
+GI_HD void wwalk_push(WWalk& k, int32_t child) { k.hi = (k.hi << 8) | (k.lo >> 56); k.lo = (k.lo << 8) | k.m; k.node = child; }
+GI_HD void wwalk_pop(WWalk& k, int32_t parent) { k.m = (uint32_t)(k.lo & 0xffull); k.lo = (k.lo >> 8) | (k.hi << 56); k.hi >>= 8; k.node = parent; }
+// next non-empty leaf whose box the ray touches, or false when the tree is exhausted; leaf = (its parent's record, slot)
+template <class WN>
+GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0, int32_t& lnode, int& lslot, int32_t& first, int32_t& cnt)
+{
+    for (;;) {
+        if (k.m == 0) {
+            if (k.node == 0) return false;
+            const int32_t par = W.with(k.node, [&](const WNode* w) { return w->parent; });
+            wwalk_pop(k, par);
+            continue;
+        }
+        const int kk = __builtin_ctz(k.m);
+        k.m &= k.m - 1;
+        const int slot = kk ^ wr.a;
+        int32_t ca = 0, cb = 0;
+        W.with(k.node, [&](const WNode* w) { ca = w->ca[slot]; cb = w->cb[slot]; return 0; });
+        if (cb < 0) {
+            wwalk_push(k, ca);
+            k.m = W.with(ca, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+            continue;
+        }
+        lnode = k.node; lslot = slot; first = ca; cnt = cb;
+        return true;
+    }
+}
+template <class WN>
+GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0)
+{
+    k.node = 0; k.m = 0; k.lo = 0; k.hi = 0;
+    const TNode& root = S.tnodes[0];
+    if (!box_hit(root.bmin, root.bmax, ray, tmin0, tmax0)) return false;
+    k.m = W.with(0, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+    return true;
+}
+template <int FEAT, class WN>
+GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best)
+{
+    const WRay wr = wray_make(ray);
+    bool intersected = false;
+    double best_d2 = 0;
+    WWalk k;
+    if (!wwalk_begin(S, W, k, ray, wr, 0.0, INFINITY)) return false;
+    for (;;) {
+        int32_t lnode = 0, first = 0, cnt = 0;
+        int lslot = 0;
+        if (!wwalk_next_leaf(W, k, ray, wr, 0.0, INFINITY, lnode, lslot, first, cnt)) break;
+        bool term = false;
+        auto test = [&](const LeafTri& g) {
+            const int32_t ti = g.tri;
+            double u, v;
+            V3 hp;
+            if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return;
+            if (!(g.matflags & 2u)) {
+                const Mat& m = S.mats[g.matflags >> 3];
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) return;
+            }
+            double d2 = len2(hp - ray.o);
+            if (!intersected || d2 < best_d2) {
+                best.pos = hp; best.u = u; best.v = v; best.tri = ti;
+                best_d2 = d2;
+                intersected = true;
+                double lmin[3], lmax[3];
+                W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
+                if (box_contains(lmin, lmax, hp)) term = true;
+            }
+        };
+        for (int32_t j = 0; j < cnt; j += 2) {
+            const LeafTri g0 = S.leaf_tris[first + j];
+            const LeafTri g1 = S.leaf_tris[first + (j + 1 < cnt ? j + 1 : j)];
+            test(g0);
+            if (j + 1 < cnt) test(g1);
+        }
+        if (term) break;
+    }
+    return intersected;
+}
+template <int FEAT, class WN>
+GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index)
+{
+    const WRay wr = wray_make(ray);
+    const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
+    WWalk k;
+    if (wwalk_begin(S, W, k, ray, wr, 0.0, tmax)) {
+        for (;;) {
+            int32_t lnode = 0, first = 0, cnt = 0;
+            int lslot = 0;
+            if (!wwalk_next_leaf(W, k, ray, wr, 0.0, tmax, lnode, lslot, first, cnt)) break;
+            for (int32_t j = 0; j < cnt; j++) {
+                const LeafTri& g = S.leaf_tris[first + j];
+                const int32_t ti = g.tri;
+                double u, v;
+                V3 hp;
+                if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) continue;
+                if (!(g.matflags & 2u)) {
+                    const Mat& m = S.mats[g.matflags >> 3];
+                    if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                }
+                double ts = len2(hp - ray.o);
+                if ((ts < mt) && (ts > 0)) return false;
+            }
+        }
+    }
+    if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:308-316
+        double tmin = 0, tmx = mt;
+        if (atmosphere_bounds(S, ray, tmin, tmx)) {
+            V3 fh, fc;
+            if (raymarch(S, ray, fh, fc, tmin, tmx, rng, P_FOG_SHADOW + 16u * light_index)) return false;
+        }
+    }
+    return true;
+}
+
 // RayTracer::trace.  Leaves are met in the order the reference's t0-sorted list has them because the hit/skip links of a
 // direction octant visit the children of every node front to back; the walk stops after the first leaf that contains a new
 // nearest hit.  Control flow is "while-while": an inner loop walks nodes until THIS lane stands on a non-empty leaf, then the
@@ -465,6 +668,8 @@ struct GlobalNodes {
 template <int FEAT, class Nodes>
 GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
+    if constexpr (Nodes::kWide) return trace_wide<FEAT>(S, N, ray, rng, alpha_purpose, best);
+    else {
     const int oct = dir_octant(ray);
     bool intersected = false;
     double best_d2 = 0;
@@ -517,9 +722,15 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
         if (term) break;
     }
     return intersected;
+    }
 }
 GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
+    if (S.wnodes && !c) {   // the work counters count the reference's per-node box tests: counted runs take the per-node walk
+        GlobalWide W;
+        W.g = S.wnodes;
+        return trace_nodes<3>(S, W, ray, rng, alpha_purpose, best, nullptr);
+    }
     GlobalNodes N;
     N.g = S.tnodes;
     return trace_nodes<3>(S, N, ray, rng, alpha_purpose, best, c);
@@ -529,6 +740,8 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
 template <int FEAT, class Nodes>
 GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
+    if constexpr (Nodes::kWide) return visible_wide<FEAT>(S, N, ray, mt, rng, light_index);
+    else {
     const int oct = dir_octant(ray);
     const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
     int32_t node = 0;
@@ -570,9 +783,15 @@ GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double 
         }
     }
     return true;
+    }
 }
 GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
+    if (S.wnodes && !c) {
+        GlobalWide W;
+        W.g = S.wnodes;
+        return visible_nodes<3>(S, W, ray, mt, rng, light_index, nullptr);
+    }
     GlobalNodes N;
     N.g = S.tnodes;
     return visible_nodes<3>(S, N, ray, mt, rng, light_index, c);
@@ -859,6 +1078,11 @@ GI_HD bool stage_trace_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_
 }
 GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
+    if (S.wnodes && !c) {
+        GlobalWide W;
+        W.g = S.wnodes;
+        return stage_trace_nodes<3>(S, W, p, seed, nullptr);
+    }
     GlobalNodes N;
     N.g = S.tnodes;
     return stage_trace_nodes<3>(S, N, p, seed, c);
@@ -946,6 +1170,11 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
 }
 GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
+    if (S.wnodes && !c) {
+        GlobalWide W;
+        W.g = S.wnodes;
+        return stage_shade_nodes<3>(S, W, p, seed, nullptr);
+    }
     GlobalNodes N;
     N.g = S.tnodes;
     return stage_shade_nodes<3>(S, N, p, seed, c);

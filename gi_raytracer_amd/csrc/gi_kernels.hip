@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gi_hip.h"
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_render(Scene S, Frame F, void* out
 extern __shared__ __align__(128) unsigned char gi_dyn_lds[];
 #define GI_LDS_NODES 512                      // 64 KB of 128-byte records
 struct LdsNodes {
+    static constexpr bool kWide = false;
     const TNode* g;
     int32_t n_l;
     __device__ __forceinline__ void fetch(int32_t i, int oct, NodeView& v) const
@@ -109,6 +111,33 @@ __device__ __forceinline__ LdsNodes stage_nodes_in_lds(const Scene& S)
     __syncthreads();
     return N;
 }
+
+// the same for the wide records (gi_device.h: WNode): 292 of them = every inner node of the BASELINE scenes
+#define GI_LDS_WNODES 292                     // 64 KB of 224-byte records
+struct LdsWide {
+    static constexpr bool kWide = true;
+    const WNode* g;
+    int32_t n_l;
+    template <class F> __device__ __forceinline__ auto with(int32_t i, F&& f) const
+    {
+        if (i < n_l) return f(reinterpret_cast<const WNode*>(gi_dyn_lds) + i);
+        return f(g + i);
+    }
+};
+__device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S)
+{
+    LdsWide N;
+    N.g = S.wnodes;
+    N.n_l = S.n_wnode < GI_LDS_WNODES ? S.n_wnode : GI_LDS_WNODES;
+    const uint4* src = reinterpret_cast<const uint4*>(S.wnodes);
+    uint4* dst = reinterpret_cast<uint4*>(gi_dyn_lds);
+    for (int i = threadIdx.x; i < N.n_l * (int)(sizeof(WNode) / 16); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return N;
+}
+template <int WIDE> struct LdsSrc;
+template <> struct LdsSrc<0> { typedef LdsNodes type; static __device__ __forceinline__ LdsNodes stage(const Scene& S) { return stage_nodes_in_lds(S); } };
+template <> struct LdsSrc<1> { typedef LdsWide type; static __device__ __forceinline__ LdsWide stage(const Scene& S) { return stage_wide_in_lds(S); } };
 
 // ================================================================================================= wavefront pipeline
 // The frame is rendered in rounds.  In a round every pixel that still wants samples (adaptive loop of RayTracer::run,
@@ -324,12 +353,12 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec
 
 #define GI_TRACE_BLOCK 1024
 #define GI_SHADE_BLOCK 512
-template <int FEAT>
+template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf)
 {
-    const LdsNodes N = stage_nodes_in_lds(S);
+    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = n_a + n_b;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
@@ -367,11 +396,11 @@ __device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& 
     return (oct << 24) | (m << 6) | db;
 }
 
-template <int FEAT>
+template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
 {
-    const LdsNodes N = stage_nodes_in_lds(S);
+    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);
     const uint32_t n_in = ctl->n_shade;
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
@@ -478,7 +507,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
 // such bounces, so the finisher runs in stages: stage k gives each wave `lanes` paths (lanes 0..lanes-1, the rest idle),
 // advances them at most `max_bounces` vertices, and hands the survivors to stage k+1, which spreads them thinner.  The
 // survivor count stays on the device (n_in_dev): no host round trip between stages.
-template <int FEAT>
+template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                         const uint32_t* q_in, const unsigned int* n_in_dev, uint32_t n_in_host, int lanes, int max_bounces,
                                                         uint32_t* q_out, unsigned int* n_out, double* lbuf)
@@ -492,8 +521,8 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, 
     for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
         const uint32_t slot = q_in[i];
         PathRec p = pool[slot];
-        GlobalNodes N;
-        N.g = S.tnodes;
+        typename std::conditional<WIDE != 0, GlobalWide, GlobalNodes>::type N;
+        if constexpr (WIDE != 0) N.g = S.wnodes; else N.g = S.tnodes;
         bool alive = true;
         for (int b = 0;;) {
             if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; break; }
@@ -658,6 +687,9 @@ struct gi_ctx {
     bool have_scene = false;
     Scene S{};
     DevBuf<TNode> d_tnodes;
+    DevBuf<WNode> d_wnodes;
+    DevBuf<int32_t> d_wleaf_id;
+    bool wide_enabled = true;         // gi_set_wide_nodes
     DevBuf<int32_t> d_refs;
     DevBuf<LeafTri> d_leaf_tris;
     DevBuf<TriGeom> d_tris;
@@ -793,6 +825,8 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     if (!layout_scene(d, H, err)) return fail(c, GI_E_INVALID, err);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, c->d_tnodes.upload(H.tnodes));
+    HIP_TRY(c, c->d_wnodes.upload(H.wnodes));
+    HIP_TRY(c, c->d_wleaf_id.upload(H.wleaf_id));
     HIP_TRY(c, c->d_refs.upload(H.refs));
     HIP_TRY(c, c->d_leaf_tris.upload(H.leaf_tris));
     HIP_TRY(c, c->d_tris.upload(H.tris));
@@ -805,6 +839,9 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.leaf_tris = c->d_leaf_tris.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
     S.mats = c->d_mats.p; S.lights = c->d_lights.p;
     S.n_node = H.n_node; S.n_tri = H.n_tri; S.n_light = H.n_light;
+    S.n_wnode = (int32_t)H.wnodes.size();
+    S.wnodes = (c->wide_enabled && S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
+    S.wleaf_id = c->d_wleaf_id.p;
     S.has_spheres = 0;
     S.fogs = c->d_fogs.p; S.fog_grid = c->d_fog_grid.p; S.n_fog = H.n_fog();
     for (const TriGeom& g : H.tris) if (g.flags & 4u) S.has_spheres = 1;
@@ -994,10 +1031,11 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0, g_finish = 0;
     const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
     if (!g_trace) {
-        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<3>, lds_nodes, GI_TRACE_BLOCK);
-        g_shade = grid_for(c, (const void*)k_st_shade<3>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<3>);
+        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<3, 1>, lds_nodes, GI_TRACE_BLOCK);
+        g_shade = grid_for(c, (const void*)k_st_shade<3, 1>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<3, 1>);
     }
     hipStream_t st = c->stream;
+    const bool wide = c->S.wnodes != nullptr;
     PathRec* pool = c->d_pool.p;
     StreamCtl* ctl = c->d_ctl.p;
     uint32_t* q_new = c->d_qs[0].p;
@@ -1046,7 +1084,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
                     const int lanes = c->finish_plan[k].first, vertices = k + 1 == n_stage ? GI_MAX_DEPTH + 1 : c->finish_plan[k].second;
                     const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
                     stage_begin(c, STG_FINISH);
-                    hipLaunchKernelGGL(fogf ? k_st_finish<3> : (sphf ? k_st_finish<GI_FEAT_SPHERES> : k_st_finish<0>), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
+                    hipLaunchKernelGGL(wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
                                        fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, c->d_lbuf.p);
                     stage_end(c);
                     launches++;
@@ -1057,9 +1095,9 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
             uint32_t* qfree_out = q_free[ping];
             const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0;
-            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(sph ? k_st_trace<GI_FEAT_SPHERES> : k_st_trace<0>, dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
                                q_shade, qfree_out, c->d_lbuf.p); stage_end(c);
-            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(fog ? k_st_shade<3> : (sph ? k_st_shade<GI_FEAT_SPHERES> : k_st_shade<0>), dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
+            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
                                qfree_out, c->d_lbuf.p); stage_end(c);
             launches += 2;
             HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
@@ -1113,6 +1151,14 @@ int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_
     // fixed sample count: streaming pool with path regeneration; adaptive sampling: synchronous rounds (sample-order decisions)
     if (c->render_mode == 0 && F.min_samples == F.max_samples && F.max_samples > 0) return render_streaming(c, F, d_out, out_is_f64, d_spp, cancel);
     return render_wavefront(c, F, d_out, out_is_f64, d_spp, cancel);
+}
+
+int gi_set_wide_nodes(gi_ctx* c, int enable)
+{
+    if (!c) return GI_E_INVALID;
+    c->wide_enabled = enable != 0;
+    c->S.wnodes = (c->wide_enabled && c->S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
+    return c->S.wnodes ? 1 : 0;
 }
 
 int gi_set_render_mode(gi_ctx* c, int mode)

@@ -21,6 +21,8 @@ namespace gi {
 
 struct HostScene {
     std::vector<TNode> tnodes;
+    std::vector<WNode> wnodes;        // empty when the tree is not made of exact octants (layout_wide)
+    std::vector<int32_t> wleaf_id;
     std::vector<int32_t> refs;
     std::vector<LeafTri> leaf_tris;
     std::vector<TriGeom> tris;
@@ -145,6 +147,78 @@ inline void link_octant(const gi_scene_desc* d, int a, int node, int32_t skip_to
     for (int i = 0; i < nk; i++) link_octant(d, a, kids[i], i + 1 < nk ? rec_of[kids[i + 1]] : skip_to, rec_of, out);
 }
 
+// Wide records (gi_device.h: WNode) for the inner nodes, breadth first.  Every existing child's box must be, bit for bit, the
+// octant Octree::Node::partition gives it (include/octree.cpp:318-328): low side [min, mid], high side [lo2, hi2], child 7
+// [mid, max], with one value of mid / lo2 / hi2 per axis and node.  Returns false (and leaves H.wnodes empty) for any other tree.
+inline bool layout_wide(const gi_scene_desc* d, HostScene& H)
+{
+    H.wnodes.clear(); H.wleaf_id.clear();
+    const int N = d->n_node;
+    auto inner = [&](int n) { for (int k = 0; k < 8; k++) if (d->node_child[(size_t)n * 8 + k] >= 0) return true; return false; };
+    if (N < 1 || !inner(0)) return false;
+    std::vector<int32_t> wrec((size_t)N, -1), order, depth((size_t)N, 0);
+    wrec[0] = 0; order.push_back(0);
+    for (size_t head = 0; head < order.size(); head++) {
+        const int n = order[head];
+        for (int k = 0; k < 8; k++) {
+            const int ch = d->node_child[(size_t)n * 8 + k];
+            if (ch < 0 || !inner(ch)) continue;
+            depth[ch] = depth[n] + 1;
+            if (depth[ch] > 15) return false;          // the walk keeps one mask byte per level in 128 bits
+            wrec[ch] = (int32_t)order.size();
+            order.push_back(ch);
+        }
+    }
+    std::vector<WNode> W(order.size());
+    std::vector<int32_t> L(order.size() * 8, -1);
+    for (WNode& w : W) { memset(&w, 0, sizeof w); w.parent = -1; }
+    for (size_t r = 0; r < order.size(); r++) {
+        const int n = order[r];
+        WNode& w = W[r];
+        const double* pb = d->node_bbox + (size_t)n * 6;
+        for (int ax = 0; ax < 3; ax++) {
+            const double mn = pb[ax], mx = pb[3 + ax];
+            // the values partition() computes; replaced below by what the children's boxes actually hold
+            double mid = mn * 0.5 + mx * 0.5, lo2 = mn + .5 * (mx - mn), hi2 = mid + .5 * (mx - mn);
+            bool have_mid = false, have_hi = false;
+            const int bitpos = ax == 0 ? 0 : (ax == 1 ? 2 : 1);   // slot bit of this axis: x = bit 0, z = bit 1, y = bit 2
+            for (int c = 0; c < 8; c++) {
+                const int ch = d->node_child[(size_t)n * 8 + c];
+                if (ch < 0) continue;
+                const double clo = d->node_bbox[(size_t)ch * 6 + ax], chi = d->node_bbox[(size_t)ch * 6 + 3 + ax];
+                const int b = (c >> bitpos) & 1;
+                if (c == 7) {
+                    if (chi != mx) return false;
+                    if (have_mid && clo != mid) return false;
+                    mid = clo; have_mid = true;
+                } else if (b == 0) {
+                    if (clo != mn) return false;
+                    if (have_mid && chi != mid) return false;
+                    mid = chi; have_mid = true;
+                } else {
+                    if (have_hi && (clo != lo2 || chi != hi2)) return false;
+                    lo2 = clo; hi2 = chi; have_hi = true;
+                }
+            }
+            w.pl[ax][0] = mn; w.pl[ax][1] = mid; w.pl[ax][2] = lo2; w.pl[ax][3] = hi2; w.pl[ax][4] = mx; w.pl[ax][5] = mid;
+        }
+        for (int c = 0; c < 8; c++) {
+            const int ch = d->node_child[(size_t)n * 8 + c];
+            if (ch < 0) continue;
+            if (inner(ch)) { w.ca[c] = wrec[ch]; w.cb[c] = -1; w.exists |= 1u << c; W[(size_t)wrec[ch]].parent = (int32_t)r; }
+            else {
+                const int cnt = d->node_ent_off[ch + 1] - d->node_ent_off[ch];
+                w.ca[c] = d->node_ent_off[ch]; w.cb[c] = cnt;
+                if (cnt > 0) w.exists |= 1u << c;
+                L[r * 8 + c] = ch;
+            }
+        }
+    }
+    H.wnodes.swap(W);
+    H.wleaf_id.swap(L);
+    return true;
+}
+
 inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
 {
     if (!validate_scene(d, err)) return false;
@@ -177,6 +251,7 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         t.leaf_id = n;
     }
     for (int a = 0; a < 8; a++) link_octant(d, a, 0, N, rec_of, H.tnodes);
+    layout_wide(d, H);
     H.refs.assign(d->node_ent_idx, d->node_ent_idx + d->node_ent_off[d->n_node]);
     H.tris.resize((size_t)d->n_tri);
     H.shade.resize((size_t)d->n_tri);

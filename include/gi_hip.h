@@ -106,6 +106,12 @@ int gi_render_host(gi_ctx*, const gi_render_params*, void* h_out_lin, int out_is
  * path queues in HBM; fixed-spp frames refill finished slots with new samples, adaptive frames run in synchronous rounds),
  * 1 = megakernel (one lane keeps one pixel, whole path in registers), 2 = wavefront in synchronous rounds always.            */
 int gi_set_render_mode(gi_ctx*, int mode);
+/* Octree walk: 1 (default) = wide records, the boxes of a node's children tested together from the five planes per axis that
+ * Octree::Node::partition builds them from (include/octree.cpp:318-328); 0 = one box test per node record.  Same box
+ * arithmetic (include/bbox.h:47-73), same visiting order, same results; a tree whose children are not those exact octants
+ * always takes the per-node walk.  Exists so that the two can be compared.  Returns 1 when the wide walk is in use after the
+ * call (a scene is uploaded and its tree qualifies), 0 when not, negative on error.                                          */
+int gi_set_wide_nodes(gi_ctx*, int enable);
 /* Upper bound on paths in flight in the wavefront pipeline (224 B each).  Default: as many as 80 % of the free HBM holds,
  * up to the whole frame (1080p x 256 spp = 531 M paths = 119 GB).                                                           */
 int gi_set_pool_slots(gi_ctx*, int64_t slots);

@@ -37,6 +37,7 @@ def lib():
         L.emul_halton_index.restype = C.c_uint32
         L.emul_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.emul_rng.restype = C.c_double
+        L.emul_set_wide.argtypes = [vp, C.c_int]
         _LIB = L
     return _LIB
 
@@ -106,6 +107,10 @@ class EmulRayTracer(gi.RayTracer):
 
     def counters(self):
         return self._last_counters
+
+    def set_wide_nodes(self, on):
+        """Returns whether the wide-record walk is in use afterwards (False: the tree is not made of exact octants)."""
+        return bool(self.E.emul_set_wide(self.h, 1 if on else 0))
 
     def trace(self, rays):
         rays = gi._f64(rays).reshape(-1, 6); n = len(rays)

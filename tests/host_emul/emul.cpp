@@ -18,11 +18,15 @@ struct Emul {
     std::vector<uint16_t> htable;
     Scene S{};
     std::string err;
+    bool wide = true;
     void bind()
     {
         S.tnodes = hs.tnodes.data(); S.leaf_refs = hs.refs.data(); S.leaf_tris = hs.leaf_tris.data(); S.tris = hs.tris.data(); S.shade = hs.shade.data();
         S.mats = hs.mats.data(); S.lights = hs.lights.data();
         S.n_node = hs.n_node; S.n_tri = hs.n_tri; S.n_light = hs.n_light; S.has_spheres = 1;
+        S.n_wnode = (int32_t)hs.wnodes.size();
+        S.wnodes = (wide && S.n_wnode > 0) ? hs.wnodes.data() : nullptr;
+        S.wleaf_id = hs.wleaf_id.data();
         S.fogs = hs.fogs.data(); S.fog_grid = hs.fog_grid.data(); S.n_fog = hs.n_fog();
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];
         S.pnodes = hp.nodes.data(); S.pranges = hp.ranges.data(); S.ph_pos = hp.pos.data(); S.ph_dircol = hp.dircol.data();
@@ -35,6 +39,7 @@ extern "C" {
 
 Emul* emul_create() { Emul* e = new Emul(); build_halton_tables(e->hdims, e->htable); e->bind(); return e; }
 void emul_destroy(Emul* e) { delete e; }
+int emul_set_wide(Emul* e, int on) { e->wide = on != 0; e->bind(); return e->S.wnodes != nullptr; }
 const char* emul_error(Emul* e) { return e->err.c_str(); }
 int emul_upload_scene(Emul* e, const gi_scene_desc* d)
 {

@@ -140,3 +140,53 @@ def check_stripes(rt, scene, w, h, spp, world, stripe_h):
 
 
 from gi_raytracer_amd.sharding import stripe_rows  # noqa: E402  (re-exported for the tests)
+
+
+def adversarial_rays(scene, n=6000, seed=5):
+    """Rays that stress the box arithmetic of the octree walk: random ones, axis-parallel ones (a zero direction component makes
+    invDir infinite and 0 * inf = NaN when the origin lies on a plane), origins exactly on node planes, and -0.0 components."""
+    t = scene.tables()
+    bb = t["node_bbox"]
+    rs = np.random.RandomState(seed)
+    lo, hi = bb[0, :3], bb[0, 3:]
+    o = lo + (hi - lo) * (rs.rand(n, 3) * 1.4 - 0.2)
+    d = rs.randn(n, 3)
+    k = n // 6
+    for j in range(k):                              # axis-parallel and plane-parallel directions
+        d[j, rs.randint(3)] = 0.0
+    for j in range(k, 2 * k):
+        a = rs.randint(3)
+        d[j] = 0.0
+        d[j, a] = rs.choice([-1.0, 1.0])
+    for j in range(2 * k, 3 * k):                   # origins on planes of random nodes (min / max / a child's planes)
+        nb = bb[rs.randint(len(bb))]
+        a = rs.randint(3)
+        o[j, a] = nb[a + 3 * rs.randint(2)]
+    for j in range(3 * k, 4 * k):                   # both: origin on a plane, direction inside that plane
+        nb = bb[rs.randint(len(bb))]
+        a = rs.randint(3)
+        o[j, a] = nb[a + 3 * rs.randint(2)]
+        d[j, a] = rs.choice([0.0, -0.0])
+    for j in range(4 * k, 5 * k):                   # negative zeros
+        d[j, rs.randint(3)] = -0.0
+    nrm = np.sqrt((d * d).sum(1))
+    d = d / np.where(nrm == 0, 1, nrm)[:, None]
+    return np.concatenate([o, d], 1)
+
+
+def check_wide_walk(rt, scene, set_wide):
+    """The wide-record walk and the per-node walk give identical answers (hit flag, entity, hit point bits, visibility)."""
+    rays = adversarial_rays(scene)
+    rs = np.random.RandomState(9)
+    q = np.concatenate([rays[:, :3], rays[:, :3] + rays[:, 3:] * (rs.rand(len(rays), 1) * 12 + 0.01)], 1)
+    assert set_wide(True), "the scene's octree was not accepted as exact octants"
+    hit_w, ent_w, res_w = rt.trace(rays)
+    vis_w = rt.visible(q)
+    set_wide(False)
+    hit_n, ent_n, res_n = rt.trace(rays)
+    vis_n = rt.visible(q)
+    set_wide(True)
+    assert hit_w.sum() > 100
+    assert np.array_equal(hit_w, hit_n) and np.array_equal(ent_w[hit_w > 0], ent_n[hit_n > 0])
+    assert np.array_equal(res_w[hit_w > 0].view(np.uint64), res_n[hit_n > 0].view(np.uint64))
+    assert np.array_equal(vis_w, vis_n)

@@ -35,6 +35,10 @@ def test_visible_matches_reference_table(setup):
     pc.check_visible_table(setup[2], setup[3])
 
 
+def test_wide_walk_equals_per_node_walk(setup):
+    pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
+
+
 def test_gather_matches_reference_table(setup):
     name, scene, rt, fx = setup
     if "photons" not in fx:

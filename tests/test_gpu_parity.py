@@ -38,6 +38,22 @@ def test_visible_matches_reference_table(setup):
     pc.check_visible_table(setup[2], setup[3])
 
 
+def test_wide_walk_equals_per_node_walk(setup):
+    pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
+
+
+def test_wide_and_per_node_frames_are_identical():
+    """The streaming pipeline with wide records (LDS) and with per-node records renders the same frame bit for bit."""
+    scene = pc.load_scene("caustics")
+    rt = gi.RayTracer(0).setScene(scene)
+    rt.tracePhotons(3000)
+    assert rt.set_wide_nodes(True)
+    a = rt.run(96, 54, min_samples=8, max_samples=8)
+    assert not rt.set_wide_nodes(False)
+    b = rt.run(96, 54, min_samples=8, max_samples=8)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 def test_gather_matches_reference_table(setup):
     name, scene, rt, fx = setup
     if "photons" not in fx:
