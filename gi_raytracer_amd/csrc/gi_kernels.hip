@@ -439,6 +439,33 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gkeys(Scene S, const PathRec* p
 // scans them from there -- a broadcast LDS read per candidate instead of an L2 round trip per lane.  Waves that straddle a leaf
 // boundary take the per-lane walk.  Both run g_key / g_acc / g_end, i.e. the same arithmetic in the same order.
 #define GI_GCHUNK 64
+// Pass 1 of the cooperative path keeps a lane's 32 smallest keys sorted in 32 registers and folds the candidates in 32 at a time:
+// sort the 32 new keys (bitonic network), take min(best[i], new[31 - i]) -- the 32 smallest of the 64, as a bitonic sequence --
+// and merge.  21 branch-free instructions per candidate; the LDS heap costs ~55, because with 64 lanes some lane always has to
+// sift, so the wave pays a full sift for nearly every candidate.  The result (tau = 32nd smallest float key) is the same number.
+__device__ __forceinline__ void kce(float& a, float& b) { const float lo = fminf(a, b), hi = fmaxf(a, b); a = lo; b = hi; }
+__device__ __forceinline__ void ksort32(float (&v)[32])
+{
+#pragma unroll
+    for (int k = 2; k <= 32; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int l = i ^ j;
+                if (l > i) { if ((i & k) == 0) kce(v[i], v[l]); else kce(v[l], v[i]); }
+            }
+}
+__device__ __forceinline__ void kmerge32(float (&v)[32])   // bitonic sequence -> ascending
+{
+#pragma unroll
+    for (int j = 16; j > 0; j >>= 1)
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int l = i ^ j;
+            if (l > i) kce(v[i], v[l]);
+        }
+}
 __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in)
 {
     __shared__ float heap[GI_GATHER_K * GI_BLOCK];
@@ -463,7 +490,10 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
         const int n_ranges = lf.nb_cnt;
         GatherAcc a;
         PathRec* p = valid ? &pool[vals[i]] : nullptr;
-        if (valid) g_begin(a, ld3(p->hpos), ld3(p->gdir), heap + threadIdx.x, GI_BLOCK, ncand);
+        g_begin(a, valid ? ld3(p->hpos) : v3(0, 0, 0), valid ? ld3(p->gdir) : v3(0, 0, 0), heap + threadIdx.x, GI_BLOCK, ncand);
+        float best[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) best[k] = INFINITY;
         for (int pass = 0; pass < 2; pass++) {
             for (int r = 0; r < n_ranges; r++) {
                 const PRange rg = ranges[r];
@@ -482,14 +512,38 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (valid) {
+                    if (pass == 0) {
+                        for (int32_t k0 = 0; k0 < m; k0 += 32) {
+                            float nk[32];
+#pragma unroll
+                            for (int k = 0; k < 32; k++) {
+                                const int kk = k0 + k < m ? k0 + k : m - 1;                 // wave-uniform clamp: no out-of-range LDS read
+                                const double* q = cand[wave][kk];
+                                const float key = (float)len2(v3(q[0], q[1], q[2]) - a.pos);   // same expression as g_key
+                                nk[k] = k0 + k < m ? key : INFINITY;
+                            }
+                            ksort32(nk);
+#pragma unroll
+                            for (int k = 0; k < 32; k++) best[k] = fminf(best[k], nk[31 - k]);
+                            kmerge32(best);
+                        }
+                    } else if (valid) {
                         for (int32_t k = 0; k < m; k++) {
                             const double* q = cand[wave][k];
-                            if (pass == 0) g_key(a, v3(q[0], q[1], q[2]));
-                            else g_acc(a, v3(q[0], q[1], q[2]), q + 3);
+                            g_acc(a, v3(q[0], q[1], q[2]), q + 3);
                         }
                     }
                 }
+            }
+            if (pass == 0) {
+                // tau = K-th smallest key, K = min(32, ncand) (what the heap's root holds after pass 1 of gather_in_leaf)
+                float tau = best[31];
+                if (ncand < 32) {
+                    tau = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 32; k++) tau = best[k] < INFINITY ? fmaxf(tau, best[k]) : tau;
+                }
+                a.tau = tau;
             }
         }
         if (valid) {
