@@ -495,43 +495,43 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
 #pragma unroll
         for (int k = 0; k < 32; k++) best[k] = INFINITY;
         for (int pass = 0; pass < 2; pass++) {
-            for (int r = 0; r < n_ranges; r++) {
-                const PRange rg = ranges[r];
-                for (int32_t c0 = 0; c0 < rg.count; c0 += GI_GCHUNK) {
-                    const int32_t m = min((int32_t)GI_GCHUNK, rg.count - c0);
-                    __builtin_amdgcn_wave_barrier();
-                    if ((int32_t)lane < m) {
-                        const size_t ph = (size_t)(rg.first + c0 + (int32_t)lane);
-                        const double* pp = S.ph_pos + ph * 3;
-                        cand[wave][lane][0] = pp[0]; cand[wave][lane][1] = pp[1]; cand[wave][lane][2] = pp[2];
-                        if (pass == 1) {
-                            const double* dc = S.ph_dircol + ph * 6;
-                            for (int k = 0; k < 6; k++) cand[wave][lane][3 + k] = dc[k];
-                        }
+            // the leaf's candidates as one sequence (its ranges back to back, the order gather_in_leaf visits them), 64 per step
+            for (int32_t c0 = 0; c0 < ncand; c0 += GI_GCHUNK) {
+                const int32_t m = min((int32_t)GI_GCHUNK, ncand - c0);
+                __builtin_amdgcn_wave_barrier();
+                if ((int32_t)lane < m) {
+                    int32_t off = c0 + (int32_t)lane, r = 0;
+                    while (off >= ranges[r].count) { off -= ranges[r].count; r++; }   // r < n_ranges: off < ncand = sum of the counts
+                    const size_t ph = (size_t)(ranges[r].first + off);
+                    const double* pp = S.ph_pos + ph * 3;
+                    cand[wave][lane][0] = pp[0]; cand[wave][lane][1] = pp[1]; cand[wave][lane][2] = pp[2];
+                    if (pass == 1) {
+                        const double* dc = S.ph_dircol + ph * 6;
+                        for (int k = 0; k < 6; k++) cand[wave][lane][3 + k] = dc[k];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (pass == 0) {
-                        for (int32_t k0 = 0; k0 < m; k0 += 32) {
-                            float nk[32];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (pass == 0) {
+                    for (int32_t k0 = 0; k0 < m; k0 += 32) {
+                        float nk[32];
 #pragma unroll
-                            for (int k = 0; k < 32; k++) {
-                                const int kk = k0 + k < m ? k0 + k : m - 1;                 // wave-uniform clamp: no out-of-range LDS read
-                                const double* q = cand[wave][kk];
-                                const float key = (float)len2(v3(q[0], q[1], q[2]) - a.pos);   // same expression as g_key
-                                nk[k] = k0 + k < m ? key : INFINITY;
-                            }
-                            ksort32(nk);
+                        for (int k = 0; k < 32; k++) {
+                            const int kk = k0 + k < m ? k0 + k : m - 1;                 // wave-uniform clamp: no out-of-range LDS read
+                            const double* q = cand[wave][kk];
+                            const float key = (float)len2(v3(q[0], q[1], q[2]) - a.pos);   // same expression as g_key
+                            nk[k] = k0 + k < m ? key : INFINITY;
+                        }
+                        ksort32(nk);
 #pragma unroll
-                            for (int k = 0; k < 32; k++) best[k] = fminf(best[k], nk[31 - k]);
-                            kmerge32(best);
-                        }
-                    } else if (valid) {
-                        for (int32_t k = 0; k < m; k++) {
-                            const double* q = cand[wave][k];
-                            g_acc(a, v3(q[0], q[1], q[2]), q + 3);
-                        }
+                        for (int k = 0; k < 32; k++) best[k] = fminf(best[k], nk[31 - k]);
+                        kmerge32(best);
+                    }
+                } else if (valid) {
+                    for (int32_t k = 0; k < m; k++) {
+                        const double* q = cand[wave][k];
+                        g_acc(a, v3(q[0], q[1], q[2]), q + 3);
                     }
                 }
             }
