@@ -553,11 +553,12 @@ template <class WN>
 GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0, int32_t& lnode, int& lslot, int32_t& first, int32_t& cnt)
 {
     for (;;) {
-        if (k.m == 0) {
+        // leave exhausted nodes first, in a loop of its own: the lanes of a wave then reach the box tests below together instead of
+        // one lane's ascent making the whole wave step through them
+        while (k.m == 0) {
             if (k.node == 0) return false;
             const int32_t par = W.with(k.node, [&](const WNode* w) { return w->parent; });
             wwalk_pop(k, par);
-            continue;
         }
         const int kk = __builtin_ctz(k.m);
         k.m &= k.m - 1;

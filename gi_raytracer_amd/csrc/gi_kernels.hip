@@ -487,7 +487,6 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
         const int ncand = lf.nb_photons;
         if (ncand == 0) continue;
         const PRange* ranges = S.pranges + lf.nb_off;
-        const int n_ranges = lf.nb_cnt;
         GatherAcc a;
         PathRec* p = valid ? &pool[vals[i]] : nullptr;
         g_begin(a, valid ? ld3(p->hpos) : v3(0, 0, 0), valid ? ld3(p->gdir) : v3(0, 0, 0), heap + threadIdx.x, GI_BLOCK, ncand);
