@@ -9,7 +9,7 @@ import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCN = {"test_scene": "scenes/test_scene/test.scn", "cornell": "scenes/cornell/test.scn", "caustics": "scenes/caustics/caustics.scn",
-       "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn", "fog": "scenes/fog/fog.scn"}
+       "teapot": "scenes/cornell/teapot.scn", "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn", "fog": "scenes/fog/fog.scn"}
 
 # float tolerance of the path (north_star: pixel RMSE < 1e-4 on linear radiance); measured values are ~1e-16
 RMSE_TOL = 1e-4

@@ -35,6 +35,12 @@ def test_visible_matches_reference_table(setup):
     pc.check_visible_table(setup[2], setup[3])
 
 
+def test_wide_walk_on_a_deeper_tree():
+    scene = pc.load_scene("teapot")
+    rt = el.EmulRayTracer().setScene(scene)
+    pc.check_wide_walk(rt, scene, rt.set_wide_nodes)
+
+
 def test_wide_walk_equals_per_node_walk(setup):
     pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
 

@@ -42,6 +42,22 @@ def test_wide_walk_equals_per_node_walk(setup):
     pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
 
 
+def test_glass_teapot_scene_matches_oracle():
+    """SURVEY section 8 config 4 (Cornell scene + glass teapot, 4496 triangles, 3828 octree nodes: more inner nodes than the LDS
+    holds, so the wide walk also reads records from global memory): frame against the oracle, and wide == per-node bit for bit.
+    Refraction: a <=1 ulp libm difference in a direction can flip a later hit, hence a looser bound than the 1e-9 of the other scenes."""
+    scene = pc.load_scene("teapot")
+    rt = gi.RayTracer(0).setScene(scene)
+    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000)
+    assert rmse < 1e-5 and img.mean() > 0.01
+    assert (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.01          # all but a handful of pixels agree to 1e-9
+    assert rt.set_wide_nodes(True)
+    a = rt.run(96, 54, min_samples=8, max_samples=8)
+    assert not rt.set_wide_nodes(False)
+    b = rt.run(96, 54, min_samples=8, max_samples=8)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 def test_wide_and_per_node_frames_are_identical():
     """The streaming pipeline with wide records (LDS) and with per-node records renders the same frame bit for bit."""
     scene = pc.load_scene("caustics")
