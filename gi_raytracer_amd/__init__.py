@@ -29,7 +29,9 @@ class SceneDesc(C.Structure):
     _fields_ = [("n_tri", C.c_int32), ("tri_pos", _dp), ("tri_nrm", _dp), ("tri_uv", _dp), ("tri_mat", _ip),
                 ("n_mat", C.c_int32), ("mats", _dp), ("n_light", C.c_int32), ("lights", _dp), ("ambient", C.c_double * 3),
                 ("n_node", C.c_int32), ("node_bbox", _dp), ("node_child", _ip), ("node_ent_off", _ip), ("node_ent_idx", _ip),
-                ("ent_kind", _ip), ("n_fog", C.c_int32), ("fog", _dp), ("fog_grid_off", _ip), ("fog_grid", _dp)]
+                ("ent_kind", _ip), ("n_fog", C.c_int32), ("fog", _dp), ("fog_grid_off", _ip), ("fog_grid", _dp),
+                ("n_tex", C.c_int32), ("tex_kind", _ip), ("tex_param", _dp), ("mat_tex", _ip), ("tex_pixels", C.POINTER(C.c_uint8)),
+                ("n_tex_pixel_bytes", C.c_int64)]
 
 
 class PhotonMapDesc(C.Structure):
@@ -58,6 +60,7 @@ ABI_SYMBOLS = [
     "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
+    "gih_add_texture", "gih_add_material_tex", "gih_load_png", "gih_free",
     "gih_add_light", "gih_add_sphere", "gih_add_height_fog", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
     "gih_counts", "gih_build_photon_map", "gih_get_photon_desc",
 ]
@@ -102,6 +105,10 @@ def lib():
     L.gih_last_error.restype = C.c_char_p
     L.gih_load_scn.argtypes = [vp, C.c_char_p]
     L.gih_add_material.argtypes = [vp, _dp]
+    L.gih_add_texture.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint8), C.c_int64]
+    L.gih_add_material_tex.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]
+    L.gih_load_png.argtypes = [C.c_char_p, _ip, _ip, _ip, C.POINTER(C.POINTER(C.c_uint8)), C.c_char_p, C.c_int32]
+    L.gih_free.argtypes = [vp]
     L.gih_add_triangles.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _ip]
     L.gih_add_light.argtypes = [vp, _dp, _dp, C.c_double]
     L.gih_add_sphere.argtypes = [vp, _dp, C.c_double, C.c_int32]
@@ -162,6 +169,35 @@ class Scene:
     def add_material(self, roughness, opacity, ior, diffuse, emissive=(0, 0, 0)):
         m = _f64([roughness, opacity, ior, *diffuse, *emissive])
         return self.L.gih_add_material(self.h, _p(m))
+
+    def add_color_texture(self, rgb):
+        """new texture(col) (include/material.h:10-30); returns the texture index."""
+        return self._tex(0, [*rgb, 0, 0, 0, 0, 0], None)
+
+    def add_checkerboard(self, a, b, tiles):
+        """new checkerboard(tiles, a, b) (include/material.h:32-50)."""
+        return self._tex(1, [*a, *b, tiles, 0], None)
+
+    def add_image_texture(self, rgba, tile=(1, 1), has_alpha=True):
+        """new imageTexture(file, tile) (include/material.h:52-81) from decoded pixels [h][w][4] uint8, rows top to bottom."""
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        h, w = rgba.shape[:2]
+        return self._tex(2, [tile[0], tile[1], w, h, 1 if has_alpha else 0, 0, 0, 0], rgba.reshape(-1))
+
+    def _tex(self, kind, params, pixels):
+        par = _f64(params)
+        rc = self.L.gih_add_texture(self.h, kind, _p(par), pixels.ctypes.data_as(C.POINTER(C.c_uint8)) if pixels is not None else None,
+                                    len(pixels) if pixels is not None else 0)
+        if rc < 0:
+            raise GiError(self._err())
+        return rc
+
+    def add_material_tex(self, dif_tex, em_tex, roughness, opacity, ior=1.0):
+        """new Material(tex[dif], tex[em], roughness, opacity, IOR) (include/material.h:84-100); returns the material index."""
+        rc = self.L.gih_add_material_tex(self.h, int(dif_tex), int(em_tex), float(roughness), float(opacity), float(ior))
+        if rc < 0:
+            raise GiError(self._err())
+        return rc
 
     def add_triangles(self, pos, nrm=None, uv=None, mat_idx=None):
         pos = _f64(pos).reshape(-1, 3, 3)
@@ -230,6 +266,10 @@ class Scene:
             "fog": _np_from(d.fog, (d.n_fog, 12), np.float64) if d.n_fog else np.zeros((0, 12)),
             "fog_grid_off": _np_from(d.fog_grid_off, (d.n_fog + 1,), np.int32) if d.n_fog else np.zeros(1, np.int32),
             "fog_grid": _np_from(d.fog_grid, (int(_np_from(d.fog_grid_off, (d.n_fog + 1,), np.int32)[-1]),), np.float64) if d.n_fog else np.zeros(0),
+            "tex_kind": _np_from(d.tex_kind, (d.n_tex,), np.int32) if d.n_tex else np.zeros(0, np.int32),
+            "tex_param": _np_from(d.tex_param, (d.n_tex, 8), np.float64) if d.n_tex else np.zeros((0, 8)),
+            "mat_tex": _np_from(d.mat_tex, (d.n_mat, 2), np.int32) if d.n_tex else np.zeros((0, 2), np.int32),
+            "tex_pixels": _np_from(d.tex_pixels, (int(d.n_tex_pixel_bytes),), np.uint8) if d.n_tex and d.n_tex_pixel_bytes else np.zeros(0, np.uint8),
         }
 
     def build_photon_map(self, photons):

@@ -4,13 +4,87 @@
 // compares them with dumps of the reference's own trees).
 #include "gi_host.h"
 
+#include <zlib.h>
+
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 namespace {
+
+// ---------------------------------------------------------------- PNG -> RGBA8 as QImage::pixelColor presents it
+// 8-bit, non-interlaced PNGs of colour type 0 (grey), 2 (RGB), 3 (palette, tRNS), 4 (grey + alpha), 6 (RGBA).  QImage converts none of these
+// (no gamma / colour management unless asked), so pixelColor() returns the stored channel values; 16-bit and interlaced files are
+// refused.  has_alpha = what QImage::hasAlphaChannel() reports: an alpha channel in the file or a tRNS chunk.
+inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+bool decode_png(const std::string& path, int& w, int& h, bool& has_alpha, std::vector<uint8_t>& rgba, std::string& err)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open image: " + path; return false; }
+    std::vector<unsigned char> file;
+    unsigned char buf[65536];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
+    fclose(f);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) { err = "not a PNG file: " + path; return false; }
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, plte, trns;
+    w = h = 0;
+    for (size_t pos = 8; pos + 12 <= file.size();) {
+        const uint32_t len = be32(&file[pos]);
+        const char* type = reinterpret_cast<const char*>(&file[pos + 4]);
+        if (pos + 12 + (size_t)len > file.size()) { err = "truncated PNG: " + path; return false; }
+        const unsigned char* data = &file[pos + 8];
+        if (memcmp(type, "IHDR", 4) == 0 && len >= 13) { w = (int)be32(data); h = (int)be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+        else if (memcmp(type, "PLTE", 4) == 0) plte.assign(data, data + len);
+        else if (memcmp(type, "tRNS", 4) == 0) trns.assign(data, data + len);
+        else if (memcmp(type, "IDAT", 4) == 0) idat.insert(idat.end(), data, data + len);
+        else if (memcmp(type, "IEND", 4) == 0) break;
+        pos += 12 + (size_t)len;
+    }
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768) { err = "PNG without a usable IHDR: " + path; return false; }
+    if (depth != 8 || interlace != 0) { err = "PNG must be 8 bits per channel and not interlaced: " + path; return false; }
+    int ch = 0;
+    switch (ctype) { case 0: ch = 1; break; case 2: ch = 3; break; case 3: ch = 1; break; case 4: ch = 2; break; case 6: ch = 4; break; default: err = "PNG colour type not supported: " + path; return false; }
+    const size_t stride = (size_t)w * ch;
+    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) { err = "PNG data does not inflate: " + path; return false; }
+    std::vector<unsigned char> img(stride * (size_t)h);
+    for (int y = 0; y < h; y++) {                       // undo the scanline filters (PNG spec 9.2)
+        const unsigned char* in = &raw[(stride + 1) * (size_t)y];
+        unsigned char* out = &img[stride * (size_t)y];
+        const unsigned char* up = y ? out - stride : nullptr;
+        const int ft = in[0];
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= (size_t)ch ? out[x - ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)ch) ? up[x - ch] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) { const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            else if (ft != 0) { err = "PNG filter type out of range: " + path; return false; }
+            out[x] = (unsigned char)(in[1 + x] + pred);
+        }
+    }
+    has_alpha = ctype == 4 || ctype == 6 || !trns.empty();
+    rgba.resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        unsigned char r = 0, g = 0, b = 0, a = 255;
+        const unsigned char* px = &img[i * ch];
+        if (ctype == 0) { r = g = b = px[0]; if (trns.size() >= 2 && px[0] == trns[1]) a = 0; }
+        else if (ctype == 2) { r = px[0]; g = px[1]; b = px[2]; if (trns.size() >= 6 && r == trns[1] && g == trns[3] && b == trns[5]) a = 0; }
+        else if (ctype == 3) { const size_t k = px[0]; if (k * 3 + 2 < plte.size()) { r = plte[k * 3]; g = plte[k * 3 + 1]; b = plte[k * 3 + 2]; } if (k < trns.size()) a = trns[k]; }
+        else if (ctype == 4) { r = g = b = px[0]; a = px[1]; }
+        else { r = px[0]; g = px[1]; b = px[2]; a = px[3]; }
+        rgba[i * 4] = r; rgba[i * 4 + 1] = g; rgba[i * 4 + 2] = b; rgba[i * 4 + 3] = a;
+    }
+    return true;
+}
 
 const int kMaxEntitiesPerLeaf = 16;    // include/util.h:14
 const int kMaxPhotonsPerLeaf = 16;     // include/util.h:15
@@ -145,6 +219,43 @@ struct gih_scene {
     std::vector<int32_t> tri_mat;
     std::vector<int32_t> ent_kind;   // 0 triangle, 1 sphere (centre = vertex 0, radius = vertex 1 x)
     std::vector<double> mats;     // 9 per material
+    // textures (include/material.h): kind, 8 parameters, RGBA8 pixel pool; mat_tex = (diffuse, emissive) texture per material, -1 for a
+    // material given as plain colours (gih_add_material)
+    std::vector<int32_t> tex_kind, mat_tex;
+    std::vector<double> tex_param;
+    std::vector<uint8_t> tex_pixels;
+    bool textured() const { for (int32_t k : tex_kind) if (k != 0) return true; return false; }
+    int add_texture(int kind, const double* p8, const uint8_t* rgba, long long n_bytes)
+    {
+        double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (kind < 0 || kind > 2 || !p8) { err = "texture: unknown kind"; return -2; }
+        for (int k = 0; k < 8; k++) q[k] = p8[k];
+        if (kind == 2) {
+            const long long w = (long long)q[2], h = (long long)q[3];
+            if (w <= 0 || h <= 0 || !rgba || n_bytes != w * h * 4) { err = "image texture: width x height x 4 bytes of RGBA expected"; return -2; }
+            q[5] = (double)tex_pixels.size();
+            tex_pixels.insert(tex_pixels.end(), rgba, rgba + n_bytes);
+        }
+        tex_kind.push_back(kind);
+        tex_param.insert(tex_param.end(), q, q + 8);
+        tree_valid = false;
+        return (int)tex_kind.size() - 1;
+    }
+    int add_material_tex(int dif, int em, double r, double o, double ior)
+    {
+        const int nt = (int)tex_kind.size();
+        if (dif < 0 || em < 0 || dif >= nt || em >= nt) { err = "mat: texture index out of range"; return -2; }
+        // the colour fields hold texture::color: the colour of a colorTex, (0, 0, 0) for the others (include/material.h:34,57)
+        const double* pd = &tex_param[(size_t)dif * 8];
+        const double* pe = &tex_param[(size_t)em * 8];
+        const bool cd = tex_kind[dif] == 0, ce = tex_kind[em] == 0;
+        const double m[9] = {r, o, ior, cd ? pd[0] : 0, cd ? pd[1] : 0, cd ? pd[2] : 0, ce ? pe[0] : 0, ce ? pe[1] : 0, ce ? pe[2] : 0};
+        mats.insert(mats.end(), m, m + 9);
+        while (mat_tex.size() < (mats.size() / 9 - 1) * 2) mat_tex.push_back(-1);
+        mat_tex.push_back(dif); mat_tex.push_back(em);
+        tree_valid = false;
+        return (int)(mats.size() / 9) - 1;
+    }
     std::vector<double> lights;   // 11 per light
     std::vector<double> fog, fog_grid;   // 12 per HeightFog; concatenated noise grids
     std::vector<int32_t> fog_grid_off = std::vector<int32_t>(1, 0);
@@ -444,7 +555,7 @@ struct gih_scene {
         const std::string dir = full.substr(0, full.find_last_of("/"));
         FILE* f = fopen(path, "r");
         if (!f) { err = std::string("cannot open scene file: ") + path; return -1; }
-        std::vector<std::vector<double>> tex;   // constant colours only
+        std::vector<int> tex;   // the scene file's texture list -> indices of this scene's texture table
         const int mat_base = (int)(mats.size() / 9);
         int n_mats_here = 0;
         char word[128];
@@ -452,20 +563,31 @@ struct gih_scene {
         for (;;) {
             if (fscanf(f, "%127s", word) == EOF) break;
             if (strcmp(word, "colorTex") == 0) {
-                double r = 0, g = 0, b = 0;
-                fscanf(f, "%lf %lf %lf\n", &r, &g, &b);
-                tex.push_back({r, g, b});
-            } else if (strcmp(word, "imTex") == 0 || strcmp(word, "checkerboardTex") == 0) {
-                err = std::string("texture keyword not supported by this build: ") + word;   // out of scope
-                rc = -2;
-                break;
+                double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                fscanf(f, "%lf %lf %lf\n", &q[0], &q[1], &q[2]);
+                tex.push_back(add_texture(0, q, nullptr, 0));
+            } else if (strcmp(word, "checkerboardTex") == 0) {   // include/sceneLoader.cpp:57-64
+                double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int tiles = 0;
+                fscanf(f, "%lf %lf %lf %lf %lf %lf %d\n", &q[0], &q[1], &q[2], &q[3], &q[4], &q[5], &tiles);
+                q[6] = tiles;
+                tex.push_back(add_texture(1, q, nullptr, 0));
+            } else if (strcmp(word, "imTex") == 0) {             // include/sceneLoader.cpp:47-56
+                char fn[100];
+                int utile = 0, vtile = 0;
+                fscanf(f, "%99s %d %d\n", fn, &utile, &vtile);
+                int w = 0, h = 0;
+                bool alpha = false;
+                std::vector<uint8_t> px;
+                if (!decode_png(dir + "/" + fn, w, h, alpha, px, err)) { rc = -2; break; }
+                const double q[8] = {(double)utile, (double)vtile, (double)w, (double)h, alpha ? 1.0 : 0.0, 0, 0, 0};
+                tex.push_back(add_texture(2, q, px.data(), (long long)px.size()));
             } else if (strcmp(word, "mat") == 0) {
                 int dif = 0, em = 0;
                 double r = 0, o = 0, ior = 1.0;   // reference: IOR uninitialised when the 5th number is missing
                 fscanf(f, "%d %d %lf %lf %lf\n", &dif, &em, &r, &o, &ior);
                 if (dif < 0 || em < 0 || dif >= (int)tex.size() || em >= (int)tex.size()) { err = "mat: texture index out of range"; rc = -2; break; }
-                const double m[9] = {r, o, ior, tex[dif][0], tex[dif][1], tex[dif][2], tex[em][0], tex[em][1], tex[em][2]};
-                mats.insert(mats.end(), m, m + 9);
+                if (add_material_tex(tex[dif], tex[em], r, o, ior) < 0) { rc = -2; break; }
                 n_mats_here++;
             } else if (strcmp(word, "multiMat") == 0) {
                 char s[128];
@@ -564,9 +686,39 @@ int gih_add_material(gih_scene* s, const double* m)
 {
     if (!s || !m) return -1;
     s->mats.insert(s->mats.end(), m, m + 9);
+    while (s->mat_tex.size() < s->mats.size() / 9 * 2) s->mat_tex.push_back(-1);   // plain colours: no texture record
     s->tree_valid = false;
     return (int)(s->mats.size() / 9) - 1;
 }
+
+int gih_add_texture(gih_scene* s, int32_t kind, const double* params8, const uint8_t* rgba, int64_t n_bytes)
+{
+    if (!s) return -1;
+    return s->add_texture(kind, params8, rgba, n_bytes);
+}
+int gih_add_material_tex(gih_scene* s, int32_t dif, int32_t em, double roughness, double opacity, double ior)
+{
+    if (!s) return -1;
+    return s->add_material_tex(dif, em, roughness, opacity, ior);
+}
+int gih_load_png(const char* path, int32_t* width, int32_t* height, int32_t* has_alpha, uint8_t** rgba_out, char* errbuf, int32_t err_len)
+{
+    if (!path || !width || !height || !has_alpha || !rgba_out) return -1;
+    int w = 0, h = 0;
+    bool a = false;
+    std::vector<uint8_t> px;
+    std::string err;
+    if (!decode_png(path, w, h, a, px, err)) {
+        if (errbuf && err_len > 0) { strncpy(errbuf, err.c_str(), (size_t)err_len - 1); errbuf[err_len - 1] = 0; }
+        return -2;
+    }
+    *width = w; *height = h; *has_alpha = a ? 1 : 0;
+    *rgba_out = (uint8_t*)malloc(px.size());
+    if (!*rgba_out) return -3;
+    memcpy(*rgba_out, px.data(), px.size());
+    return 0;
+}
+void gih_free(void* p) { free(p); }
 
 int gih_add_triangles(gih_scene* s, int32_t n, const double* pos, const double* nrm, const double* uv, const int32_t* mat_idx)
 {
@@ -651,6 +803,12 @@ int gih_get_scene_desc(const gih_scene* s, gi_scene_desc* d)
     d->ent_kind = s->ent_kind.data();
     d->n_fog = (int32_t)(s->fog.size() / 12);
     d->fog = s->fog.data(); d->fog_grid_off = s->fog_grid_off.data(); d->fog_grid = s->fog_grid.data();
+    if (s->textured()) {   // constant-colour scenes stay in the plain form (n_tex = 0)
+        if (s->mat_tex.size() != (size_t)d->n_mat * 2) return -4;   // a material added as plain colours next to textured ones
+        d->n_tex = (int32_t)s->tex_kind.size();
+        d->tex_kind = s->tex_kind.data(); d->tex_param = s->tex_param.data(); d->mat_tex = s->mat_tex.data();
+        d->tex_pixels = s->tex_pixels.data(); d->n_tex_pixel_bytes = (int64_t)s->tex_pixels.size();
+    }
     return 0;
 }
 

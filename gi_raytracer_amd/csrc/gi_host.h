@@ -29,6 +29,14 @@ int gih_load_scn(gih_scene*, const char* path);
 
 /* programmatic construction = Octree::push_back (include/octree.cpp:25-50) */
 int gih_add_material(gih_scene*, const double* mat9);                 /* returns the material index */
+/* textures (include/material.h:10-81): kind and params8 as gi_scene_desc::tex_kind / tex_param; an image (kind 2) passes its
+ * width x height RGBA8 pixels (rows top to bottom) and params8 = tile u, tile v, width, height, has alpha; returns the texture
+ * index.  gih_add_material_tex = new Material(tex[dif], tex[em], roughness, opacity, IOR), returns the material index.
+ * gih_load_png decodes an 8-bit, non-interlaced PNG the way QImage presents it (the loader of `imTex` lines).                */
+int gih_add_texture(gih_scene*, int32_t kind, const double* params8, const uint8_t* rgba, int64_t n_bytes);
+int gih_add_material_tex(gih_scene*, int32_t dif_tex, int32_t em_tex, double roughness, double opacity, double ior);
+int gih_load_png(const char* path, int32_t* width, int32_t* height, int32_t* has_alpha, uint8_t** rgba_out /* free with gih_free */, char* err, int32_t err_len);
+void gih_free(void*);
 int gih_add_triangles(gih_scene*, int32_t n, const double* pos, const double* nrm, const double* uv, const int32_t* mat_idx);
 int gih_add_sphere(gih_scene*, const double* centre3, double radius, int32_t mat_idx);   /* new sphere(pos, rad, mat) */
 /* new HeightFog(pos, size, col, density, scatter, noiseScale) (include/atmosphere.h:37-47): params12 as in gi_scene_desc::fog;

@@ -54,6 +54,18 @@ typedef struct gi_scene_desc {
     const double* fog;
     const int32_t* fog_grid_off;
     const double* fog_grid;
+    /* textures (include/material.h:10-81).  n_tex = 0: every material is the constant colour pair held in mats[] (colorTex).
+     * Else mat_tex [n_mat][2] = diffuse and emissive texture of each material, and texture t is
+     *   tex_kind[t] = 0  texture(col):            tex_param[t] = col rgb
+     *   tex_kind[t] = 1  checkerboard(t, a, b):   tex_param[t] = a rgb, b rgb, tiles
+     *   tex_kind[t] = 2  imageTexture(file, tile): tex_param[t] = tile u, tile v, width, height, has alpha channel (0/1), offset of
+     *                    its first pixel in tex_pixels (pixels: RGBA8, rows top to bottom as QImage addresses them)           */
+    int32_t n_tex;
+    const int32_t* tex_kind;
+    const double* tex_param;     /* [n_tex][8] */
+    const int32_t* mat_tex;      /* [n_mat][2] */
+    const uint8_t* tex_pixels;
+    int64_t n_tex_pixel_bytes;
 } gi_scene_desc;
 
 /* Photon set + linearised PhotonMap (include/photonMap.h:13-49, include/photon.h:5-15). */

@@ -32,6 +32,7 @@ const double SHADOW_BIAS = 0.0001;
 const int MIN_DEPTH = 2;
 const int MAX_DEPTH = 64;
 const double RAYMARCH_STEPSIZE = 0.04;
+const double GAMMA_ = 2.2;                  // include/util.h:31
 const double PI = 3.14159265358979323846;  // glibc M_PI (util.h's fallback #define is not taken)
 
 // ----------------------------------------------------------------------------- vec3 with glm operand order
@@ -421,7 +422,8 @@ struct Box {
     }
 };
 
-struct Material { double roughness, opacity, IOR; V3 diffuse, emissive; };  // include/material.h:84-100, constant textures
+struct Material { double roughness, opacity, IOR; V3 diffuse, emissive; int dtex = -1, etex = -1; };  // include/material.h:84-100; diffuse / emissive = texture::color
+struct Texture { int kind; double p[8]; };   // 0 texture(col), 1 checkerboard, 2 imageTexture (include/material.h:10-81); parameters as gi_scene_desc::tex_param
 struct Entity {
     int kind;       // 0 triangle, 1 sphere
     V3 p[3], n[3];  // triangle vertices / normals; sphere: p[0] centre, p[1].x radius
@@ -536,6 +538,8 @@ struct Counters { int64_t v_trace = 0, v_shadow = 0, tri = 0, shaded = 0, pcand 
 struct gio_ctx {
     std::vector<Entity> ents;
     std::vector<Material> mats;
+    std::vector<Texture> texs;
+    std::vector<unsigned char> tex_pixels;
     std::vector<Light> lights;
     std::vector<Fog> fogs;
     V3 ambient = {0, 0, 0};
@@ -710,7 +714,38 @@ struct gio_ctx {
         return false;
     }
 
-    double mat_alpha(const Material& m) const { return m.opacity * 1.0; }  // Material::getAlpha with a constant texture, material.h:90-93
+    // texture::get / checkerboard::get / imageTexture::get (include/material.h:18-21,38-44,63-68)
+    V3 tex_get(int t, V3 constant, V2 uv) const
+    {
+        if (t < 0) return constant;
+        const Texture& x = texs[(size_t)t];
+        if (x.kind == 0) return v3(x.p[0], x.p[1], x.p[2]);
+        if (x.kind == 1) {
+            const int tiles = (int)x.p[6];
+            if (((int)(uv.x * tiles) % 2 == 0) ^ ((int)(uv.y * tiles) % 2 == 0)) return v3(x.p[0], x.p[1], x.p[2]);
+            return v3(x.p[3], x.p[4], x.p[5]);
+        }
+        const unsigned char* px = tex_pixel(x, uv);
+        // gamma({r/255, g/255, b/255}, 1.0/GAMMA) = pow(c, 1.0 / (1.0/GAMMA)), include/util.h:94-97
+        const double g = 1.0 / GAMMA_;
+        return v3(std::pow(px[0] / 255.0, 1.0 / g), std::pow(px[1] / 255.0, 1.0 / g), std::pow(px[2] / 255.0, 1.0 / g));
+    }
+    // texture::getAlpha / imageTexture::getAlpha (include/material.h:23-26,70-78)
+    double tex_alpha(int t, V2 uv) const
+    {
+        if (t < 0) return 1;
+        const Texture& x = texs[(size_t)t];
+        if (x.kind != 2 || x.p[4] == 0) return 1;
+        return tex_pixel(x, uv)[3] / 255.0;
+    }
+    const unsigned char* tex_pixel(const Texture& x, V2 uv) const   // image.pixelColor(...), include/material.h:65
+    {
+        const int w = (int)x.p[2], h = (int)x.p[3];
+        const int px = std::abs((int)(uv.x * w * x.p[0]) % w);
+        const int py = h - std::abs((int)(uv.y * h * x.p[1]) % h) - 1;
+        return &tex_pixels[(size_t)x.p[5] + ((size_t)py * w + px) * 4];
+    }
+    double mat_alpha(const Material& m, V2 uv) const { return m.opacity * tex_alpha(m.dtex, uv); }  // Material::getAlpha, material.h:90-93
 
     // RayTracer::trace, include/raytracer.h:382-478.  alpha_purpose selects the counter-RNG purpose of the alpha draws.
     bool trace(const Ray& ray, Hit& minHit, int& obj, Rng& rng, Counters* c, int* n_leaves = nullptr, uint32_t alpha_purpose = P_TRACE_ALPHA) const
@@ -731,7 +766,7 @@ struct gio_ctx {
             for (int ei : cur.ents) {
                 const Entity& e = ents[ei];
                 if (c) c->tri++;
-                if (ent_intersect(e, ray, h) && (rng.draw(alpha_purpose, (uint32_t)nodes[nd].first, (uint32_t)ei) < mat_alpha(mats[e.mat]) || mats[e.mat].IOR != 1)) {
+                if (ent_intersect(e, ray, h) && (rng.draw(alpha_purpose, (uint32_t)nodes[nd].first, (uint32_t)ei) < mat_alpha(mats[e.mat], h.uv) || mats[e.mat].IOR != 1)) {
                     if (!intersected || len2(h.pos - ray.origin) < len2(minHit.pos - ray.origin)) {
                         current = ei;
                         minHit = h;
@@ -759,8 +794,9 @@ struct gio_ctx {
         while (!hit && k != cand.size()) {
             const Entity& e = ents[cand[k].second];
             Hit h;
+            h.uv = V2{0, 0};   // the reference's `glm::dvec2 uv;` is uninitialised here; only a flat-shaded triangle reads it before writing
             if (c) { c->tri++; c->tri_shadow++; }
-            if (ent_intersect(e, ray, h) && (rng.draw(P_SHADOW_ALPHA | (light_index << 8), (uint32_t)cand[k].first, (uint32_t)cand[k].second) < mat_alpha(mats[e.mat]) || mats[e.mat].IOR != 1)) {
+            if (ent_intersect(e, ray, h) && (rng.draw(P_SHADOW_ALPHA | (light_index << 8), (uint32_t)cand[k].first, (uint32_t)cand[k].second) < mat_alpha(mats[e.mat], h.uv) || mats[e.mat].IOR != 1)) {
                 double t_shadow = len2(h.pos - ray.origin);
                 hit = (t_shadow < mt) && (t_shadow > 0);
             }
@@ -776,11 +812,11 @@ struct gio_ctx {
     }
 
     // RayTracer::rayType, include/raytracer.h:481-506
-    int ray_type(const Material& m, const Ray& ray, V3 norm, Rng& rng) const
+    int ray_type(const Material& m, const Ray& ray, V3 norm, V2 uv, Rng& rng) const
     {
         int type = 2;
         double IOR = m.IOR;
-        double opacity = 1.0 * m.opacity;
+        double opacity = tex_alpha(m.dtex, uv) * m.opacity;
         double r0 = std::pow((1 - IOR) / (1 + IOR), 2);
         double fs = r0 + (1 - r0) * std::pow(1 - dot(reflect(ray.dir, norm), norm), 5);
         if (m.roughness < .001) type = 0;
@@ -792,13 +828,13 @@ struct gio_ctx {
     }
 
     // RayTracer::secondaryRay, include/raytracer.h:321-379
-    void secondary_ray(const Ray& ray, const Material& m, V3& norm, double sx, double sy, V3& refDir, V3& f, double& roughness, V3& contrib, double& offset, Rng& rng) const
+    void secondary_ray(const Ray& ray, const Material& m, V3& norm, V2 uv, double sx, double sy, V3& refDir, V3& f, double& roughness, V3& contrib, double& offset, Rng& rng) const
     {
         bool backface = false;
         if (dot(norm, ray.dir) > 0) { norm = norm * -1.0; backface = true; }
-        V3 color = m.diffuse;
+        V3 color = tex_get(m.dtex, m.diffuse, uv);
         roughness = m.roughness;
-        int type = ray_type(m, ray, norm, rng);
+        int type = ray_type(m, ray, norm, uv, rng);
         if (type == 1) {
             if (backface) refDir = refr(ray.dir, norm, m.IOR);
             else refDir = refr(ray.dir, norm, 1.0 / m.IOR);
@@ -953,10 +989,10 @@ struct gio_ctx {
             const Material& m = mats[ents[current].mat];
             V3 i = v3(0, 0, 0);
             V3 refDir;
-            V3 color = m.diffuse;
+            V3 color = tex_get(m.dtex, m.diffuse, mh.uv);
             double roughness = m.roughness;
             V3 f = v3(1, 1, 1);
-            secondary_ray(ray, m, mh.norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
+            secondary_ray(ray, m, mh.norm, mh.uv, sx, sy, refDir, f, roughness, contrib, offset, rng);
             {   // include/raytracer.h:209-228
                 double tmin = 0, tmax = length(mh.pos - ray.origin);
                 if (!fogs.empty() && atmosphere_bounds(ray, tmin, tmax)) {
@@ -995,7 +1031,7 @@ struct gio_ctx {
             if (depth <= MIN_DEPTH || rng.draw(P_RR) < q) {
                 f = f * (depth <= MIN_DEPTH ? 1.0 : (1.0 / q));
                 V3 next = radiance(Ray(mh.pos + offset * mh.norm, refDir), depth + 1, sample, contrib, rng, c);
-                return color * i + f * next + m.emissive + color * caustic;
+                return color * i + f * next + tex_get(m.etex, m.emissive, mh.uv) + color * caustic;
             }
             return color * i;
         }
@@ -1091,7 +1127,7 @@ struct gio_ctx {
                             double offset = SHADOW_BIAS;
                             double e13 = rng.draw(P_PH_SEC_V);
                             double e5 = rng.draw(P_PH_SEC_U);
-                            secondary_ray(r, m, h.norm, std::fmod(e5 + 5 * i, 1), std::fmod(e13 + 13 * i, 1), refDir, f, roughness, contrib, offset, rng);
+                            secondary_ray(r, m, h.norm, h.uv, std::fmod(e5 + 5 * i, 1), std::fmod(e13 + 13 * i, 1), refDir, f, roughness, contrib, offset, rng);
                             {   // include/raytracer.h:658-675
                                 double tmin = 0, tmax = length(h.pos - r.origin);
                                 if (!fogs.empty() && atmosphere_bounds(r, tmin, tmax)) {
@@ -1180,6 +1216,26 @@ int gio_set_fog(gio_ctx* c, int n, const double* params12, const int32_t* grid_o
         f.d = q[9]; f.sc = q[10]; f.nscale = 1;   // the constructor forces nscale = 1 after sizing the grid (include/atmosphere.h:46)
         f.grid.assign(grid + grid_off[i], grid + grid_off[i + 1]);
         if (f.grid.empty()) return -1;
+    }
+    return 0;
+}
+// textures as in gi_scene_desc (include/gi_hip.h): call after gio_set_scene
+int gio_set_textures(gio_ctx* c, int n_tex, const int32_t* kind, const double* param8, const int32_t* mat_tex, const uint8_t* pixels, int64_t n_bytes)
+{
+    c->texs.resize((size_t)n_tex);
+    for (int i = 0; i < n_tex; i++) { c->texs[i].kind = kind[i]; for (int k = 0; k < 8; k++) c->texs[i].p[k] = param8[(size_t)i * 8 + k]; }
+    c->tex_pixels.assign(pixels, pixels + n_bytes);
+    for (size_t m = 0; m < c->mats.size(); m++) { c->mats[m].dtex = n_tex ? mat_tex[m * 2] : -1; c->mats[m].etex = n_tex ? mat_tex[m * 2 + 1] : -1; }
+    return 0;
+}
+// known answers of texture::get / getAlpha: out [n][4] = rgb, alpha
+int gio_tex_eval(gio_ctx* c, int tex, int n, const double* uv, double* out)
+{
+    if (tex < 0 || tex >= (int)c->texs.size()) return -1;
+    for (int i = 0; i < n; i++) {
+        V2 q = V2{uv[i * 2], uv[i * 2 + 1]};
+        V3 g = c->tex_get(tex, v3(0, 0, 0), q);
+        out[i * 4] = g.x; out[i * 4 + 1] = g.y; out[i * 4 + 2] = g.z; out[i * 4 + 3] = c->tex_alpha(tex, q);
     }
     return 0;
 }

@@ -37,6 +37,9 @@ int gio_set_scene(gio_ctx*, int n_ent, const int32_t* ent_kind, const double* po
 /* HeightFog entities (include/atmosphere.h:30-83): params [n][12] = pos, size, col, density, scatter, noise scale; the noise grids
  * (the reference fills them with drand() in the constructor) are passed explicitly: grid_off [n+1] into grid.               */
 int gio_set_fog(gio_ctx*, int n, const double* params12, const int32_t* grid_off, const double* grid);
+/* textures of include/material.h:10-81 in the layout of gi_scene_desc (include/gi_hip.h); call after gio_set_scene */
+int gio_set_textures(gio_ctx*, int n_tex, const int32_t* kind, const double* param8, const int32_t* mat_tex, const uint8_t* pixels, int64_t n_bytes);
+int gio_tex_eval(gio_ctx*, int tex, int n, const double* uv, double* out_rgba);
 /* GIO_RNG_CHAIN: skip draws the reference made outside the render path (the HeightFog constructor's noise grid)              */
 int gio_chain_discard(gio_ctx*, int64_t n);
 /* camera: pos(3) up(3) forward(3) sensorDiag focalDist  (include/camera.h) */

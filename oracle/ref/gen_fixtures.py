@@ -24,6 +24,8 @@ SCENES = {
     "caustics": (f"{REF}/scenes/caustics/caustics.scn", 64, 48, 20000),
     # our own scene file with the `sphere` keyword (analytic spheres: mirror, glass, glossy), run through the reference
     "spheres": (f"{ROOT}/scenes/spheres/spheres_opaque.scn", 48, 36, 4000),
+    # checkerboard and image textures (with and without alpha), on meshes and on spheres; also pins texture::get / getAlpha on a uv lattice
+    "textures": (f"{ROOT}/scenes/textures/tex_opaque.scn", 48, 36, 1500),
 }
 CHAINS = {
     # name: (scene, W, H, spp, photons, mode)
@@ -38,6 +40,8 @@ CHAINS = {
     # HeightFog: ray-marched medium on camera segments, shadow rays and photon paths (scenes/fog/fog.scn, our scene file)
     "chain_fog_lin": (f"{ROOT}/scenes/fog/fog.scn", 40, 30, 4, 1500, "lin"),
     "chain_fog_run": (f"{ROOT}/scenes/fog/fog.scn", 40, 30, 4, 1500, "run"),
+    "chain_textures_lin": (f"{ROOT}/scenes/textures/tex.scn", 40, 30, 4, 1500, "lin"),
+    "chain_textures_run": (f"{ROOT}/scenes/textures/tex.scn", 40, 30, 4, 1500, "run"),
 }
 
 

@@ -270,6 +270,49 @@ static void dump_scene_tables(Loaded& L, const std::string& out)
     save_f64(out + "/tri_bbox.npy", ebox, {T, 6});
     save_i32(out + "/ent_kind.npy", kind, {T});
 
+    {   // textures (include/material.h:10-81): the distinct texture objects the entities' materials point to, in first-seen order, in
+        // the layout of gi_scene_desc::tex_* (include/gi_hip.h); image pixels as QImage::pixelColor returns them; and known answers of
+        // get() / getAlpha() on a uv lattice that leaves [0, 1] on both sides
+        std::vector<texture*> texs;
+        std::map<texture*, int> tex_id;
+        std::vector<int32_t> tri_tex, tkind;
+        for (Entity* e : L.ents)
+            for (texture* t : {e->material.diffuse, e->material.emissive}) {
+                if (!tex_id.count(t)) { tex_id[t] = (int)texs.size(); texs.push_back(t); }
+                tri_tex.push_back(tex_id[t]);
+            }
+        std::vector<double> tpar, kat;
+        std::vector<uint8_t> pix;
+        const int KU = 23;
+        for (texture* t : texs) {
+            checkerboard* cb = dynamic_cast<checkerboard*>(t);
+            imageTexture* im = dynamic_cast<imageTexture*>(t);
+            double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (cb) { q[0] = cb->a.x; q[1] = cb->a.y; q[2] = cb->a.z; q[3] = cb->b.x; q[4] = cb->b.y; q[5] = cb->b.z; q[6] = cb->tiles; tkind.push_back(1); }
+            else if (im) {
+                q[0] = im->tile.x; q[1] = im->tile.y; q[2] = im->image.width(); q[3] = im->image.height(); q[4] = im->image.hasAlphaChannel() ? 1 : 0; q[5] = (double)pix.size();
+                for (int y = 0; y < im->image.height(); y++)
+                    for (int x = 0; x < im->image.width(); x++) {
+                        QColor c = im->image.pixelColor(x, y);
+                        pix.push_back((uint8_t)c.red()); pix.push_back((uint8_t)c.green()); pix.push_back((uint8_t)c.blue()); pix.push_back((uint8_t)c.alpha());
+                    }
+                tkind.push_back(2);
+            } else { q[0] = t->color.x; q[1] = t->color.y; q[2] = t->color.z; tkind.push_back(0); }
+            tpar.insert(tpar.end(), q, q + 8);
+            for (int a = 0; a < KU; a++)
+                for (int b = 0; b < KU; b++) {
+                    glm::dvec2 uv(-0.75 + 0.1171875 * a, -0.6 + 0.109375 * b);
+                    glm::dvec3 g = t->get(uv);
+                    kat.insert(kat.end(), {uv.x, uv.y, g.x, g.y, g.z, t->getAlpha(uv)});
+                }
+        }
+        save_i32(out + "/tri_tex.npy", tri_tex, {T, 2});
+        save_i32(out + "/tex_kind.npy", tkind, {texs.size()});
+        save_f64(out + "/tex_param.npy", tpar, {texs.size(), 8});
+        save_u8(out + "/tex_pixels.npy", pix, {pix.size()});
+        save_f64(out + "/tex_kat.npy", kat, {texs.size(), (size_t)KU * KU, 6});
+    }
+
     std::vector<double> li;
     for (Light* l : L.scene->lights) li.insert(li.end(), {l->pos.x, l->pos.y, l->pos.z, l->col.x, l->col.y, l->col.z, l->rad, l->dir.x, l->dir.y, l->dir.z, l->angle});
     save_f64(out + "/lights.npy", li, {L.scene->lights.size(), 11});

@@ -62,6 +62,8 @@ def lib():
         L.gio_set_scene.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, c_dp, c_ip, C.c_int, c_dp, C.c_int, c_dp, c_dp]
         L.gio_set_camera.argtypes = [C.c_void_p, c_dp]
         L.gio_set_fog.argtypes = [C.c_void_p, C.c_int, c_dp, c_ip, c_dp]
+        L.gio_tex_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp]
+        L.gio_set_textures.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_ip, C.POINTER(C.c_uint8), C.c_int64]
         L.gio_chain_discard.argtypes = [C.c_void_p, C.c_int64]
         L.gio_build_octree.argtypes = [C.c_void_p]
         L.gio_chain_seed.argtypes = [C.c_void_p, C.c_uint64]
@@ -98,7 +100,7 @@ def unique_materials(tri_mat):
             seen[key] = len(mats)
             mats.append(row)
         idx[i] = seen[key]
-    return idx, np.ascontiguousarray(np.array(mats, np.float64).reshape(-1, 9))
+    return idx, np.ascontiguousarray(np.array(mats, np.float64).reshape(len(mats), -1))
 
 
 class Oracle:
@@ -137,6 +139,19 @@ class Oracle:
         assert self.L.gio_set_fog(self.h, len(params), _ptr(params, c_dp), _ptr(grid_off, c_ip), _ptr(grid, c_dp)) == 0
         return self
 
+    def set_textures(self, kind, param, mat_tex, pixels):
+        kind = np.ascontiguousarray(kind, np.int32); param = np.ascontiguousarray(param, np.float64)
+        mat_tex = np.ascontiguousarray(mat_tex, np.int32); pixels = np.ascontiguousarray(pixels, np.uint8)
+        assert self.L.gio_set_textures(self.h, len(kind), _ptr(kind, c_ip), _ptr(param, c_dp), _ptr(mat_tex, c_ip),
+                                       pixels.ctypes.data_as(C.POINTER(C.c_uint8)), len(pixels)) == 0
+        return self
+
+    def tex_eval(self, tex, uv):
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        out = np.zeros((len(uv), 4))
+        assert self.L.gio_tex_eval(self.h, int(tex), len(uv), _ptr(uv, c_dp), _ptr(out, c_dp)) == 0
+        return out
+
     def chain_discard(self, n):
         self.L.gio_chain_discard(self.h, int(n))
         return self
@@ -149,9 +164,13 @@ class Oracle:
     @classmethod
     def from_fixture(cls, fx):
         o = cls()
-        mat_idx, mats = unique_materials(fx["tri_mat"])
-        o.set_scene(fx["tri_pos"], fx["tri_nrm"], fx["tri_uv"], mat_idx, mats, fx["lights"][:, :7] if len(fx["lights"]) else np.zeros((0, 7)),
+        textured = "tex_kind" in fx and (np.asarray(fx["tex_kind"]) != 0).any()
+        rows = np.concatenate([fx["tri_mat"], fx["tri_tex"].astype(np.float64)], 1) if textured else fx["tri_mat"]
+        mat_idx, mats = unique_materials(rows)
+        o.set_scene(fx["tri_pos"], fx["tri_nrm"], fx["tri_uv"], mat_idx, np.ascontiguousarray(mats[:, :9]), fx["lights"][:, :7] if len(fx["lights"]) else np.zeros((0, 7)),
                     fx["settings"][0:3], kind=fx["ent_kind"])
+        if textured:
+            o.set_textures(fx["tex_kind"], fx["tex_param"], mats[:, 9:11].astype(np.int32), fx["tex_pixels"])
         s = fx["settings"]
         o.set_camera(s[8:11], s[11:14], s[14:17], s[20], s[21])
         if "fog" in fx and len(fx["fog"]):

@@ -9,7 +9,7 @@ import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCN = {"test_scene": "scenes/test_scene/test.scn", "cornell": "scenes/cornell/test.scn", "caustics": "scenes/caustics/caustics.scn",
-       "teapot": "scenes/cornell/teapot.scn", "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn", "fog": "scenes/fog/fog.scn"}
+       "teapot": "scenes/cornell/teapot.scn", "textures": "scenes/textures/tex.scn", "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn", "fog": "scenes/fog/fog.scn"}
 
 # float tolerance of the path (north_star: pixel RMSE < 1e-4 on linear radiance); measured values are ~1e-16
 RMSE_TOL = 1e-4
@@ -23,6 +23,8 @@ def oracle_for(scene):
     t, st = scene.tables(), scene.settings
     o = ol.Oracle().set_scene(t["tri_pos"], t["tri_nrm"], t["tri_uv"], t["tri_mat"], t["mats"], t["lights"][:, :7], t["ambient"], kind=t["ent_kind"])
     o.set_camera(list(st.cam_pos), list(st.cam_up), list(st.cam_forward), st.sensor_diag, st.focal_dist)
+    if len(t["tex_kind"]):
+        o.set_textures(t["tex_kind"], t["tex_param"], t["mat_tex"], t["tex_pixels"])
     if len(t["fog"]):
         o.set_fog(t["fog"], t["fog_grid_off"], t["fog_grid"])     # the same noise grid the product's loader generated
     return o.build_octree()

@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib as ol
 
-SCENES = ["test_scene", "cornell", "caustics", "spheres"]
+SCENES = ["test_scene", "cornell", "caustics", "spheres", "textures"]
 
 
 def P(a):
@@ -129,9 +129,23 @@ def test_photon_octree_and_gather_identical(scene):
     assert (nc == 0).any() and (nc > 32).any() and ((nc > 0) & (nc < 32)).any()  # edge cases are covered
 
 
+def test_textures_get_and_alpha_bit_exact(golden):
+    """texture::get / getAlpha of every texture of scenes/textures/tex.scn (colour, checkerboard, PNG with and without alpha channel) on a
+    uv lattice that leaves [0, 1] on both sides -- the reference's own answers, image pixels as its QImage returned them."""
+    fx = golden("scene_textures")
+    o = ol.Oracle.from_fixture(fx)
+    assert set(fx["tex_kind"].tolist()) == {0, 1, 2}
+    for t in range(len(fx["tex_kind"])):
+        k = fx["tex_kat"][t]
+        assert np.array_equal(o.tex_eval(t, k[:, :2]), k[:, 2:6]), t
+    alpha = fx["tex_kat"][np.flatnonzero(fx["tex_param"][:, 4] == 1)[0]][:, 5]
+    assert (alpha == 0).any() and (alpha == 1).any()   # partial alpha (128/255) is in tex.scn, pinned by the chain_textures_* frames
+
+
 # ------------------------------------------------------------------ whole frames on the pinned RNG chain (a-1, a-2, a-10, f1)
 @pytest.mark.parametrize("name", ["chain_test_scene_lin", "chain_caustics_lin", "chain_cornell_lin", "chain_caustics_run", "chain_cornell_run",
-                                  "chain_spheres_lin", "chain_spheres_run", "chain_fog_lin", "chain_fog_run"])
+                                  "chain_spheres_lin", "chain_spheres_run", "chain_fog_lin", "chain_fog_run",
+                                  "chain_textures_lin", "chain_textures_run"])
 def test_whole_frame_matches_reference_bit_for_bit(golden, name):
     """The reference's frame (its own RayTracer::run for *_run; radiance() per sample for *_lin) on a pinned time() and
     one OpenMP thread, including tracePhotons and the photon-map build, reproduced by the oracle's chain RNG mode."""
@@ -142,7 +156,9 @@ def test_whole_frame_matches_reference_bit_for_bit(golden, name):
         o.chain_discard(len(fx["fog_grid"]))      # the HeightFog constructor drew its noise grid from the chain at load time
     if nph > 0 and len(fx["lights"]):
         n, _ = o.emit_photons(nph, 5, ol.RNG_CHAIN)
-        assert n == len(fx["chain_photons_leaforder"])
+        o.build_photon_map()
+        # photons outside the half-open root box are emitted but sit in no leaf (textures scene: 410 of 1500)
+        assert n >= len(fx["chain_photons_leaforder"]) and len(o.pmap()[3]) == len(fx["chain_photons_leaforder"])
     o.build_photon_map()
     r = o.render(W, H, spp, rng_mode=ol.RNG_CHAIN, chain_predraws=2 if isrun else 0, want_u8=True)
     if isrun:
