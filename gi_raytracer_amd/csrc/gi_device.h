@@ -46,6 +46,7 @@ namespace gi {
 #define GI_RAYMARCH_STEPSIZE 0.04
 #define GI_FEAT_SPHERES 1   // template feature bits: code for entity kinds / media a scene does not contain is not compiled in
 #define GI_FEAT_FOG 2
+#define GI_FEAT_TEX 4       // checkerboard / image textures (include/material.h:32-81): uv carried through the walk, texture alpha in the alpha test
 
 // ------------------------------------------------------------------------------------------------ device tables (HBM layout)
 struct NodeLink { int32_t hit, skip; };
@@ -86,8 +87,15 @@ struct LeafTri {            // 80 B: the test record again, stored once per leaf
     int32_t tri;            // triangle index (shading record, RNG key)
     uint32_t matflags;      // material << 3 | flags
 };
-struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; };  // 96 B, read once per shaded hit
-struct Mat { double roughness, opacity, ior, diffuse[3], emissive[3]; };
+struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; double t0[2], t1[2], t2[2]; };  // 144 B, read once per shaded hit (t*: vertex texCoords)
+struct Mat { double roughness, opacity, ior, diffuse[3], emissive[3]; int32_t dtex, etex; };   // dtex / etex: texture record or -1 = the constant colour
+struct TexD {               // include/material.h:10-81
+    int32_t kind;           // 0 texture(col), 1 checkerboard, 2 imageTexture
+    int32_t w, h, has_alpha;
+    double a[3], b[3];      // colour; checkerboard colours a, b
+    double tiles, tile_u, tile_v;
+    unsigned long long pix; // first byte of the image in Scene::tex_pixels (RGBA8, rows top to bottom)
+};
 struct LightD { double pos[3], col[3], rad, dir[3], angle; };
 struct alignas(128) PNode { // 128 B: photon octree node; the 8 children of a node are 8 consecutive records
     double bmin[3], bmax[3];// node box: PhotonMap::Node::getBounds checks contains() at every level
@@ -117,6 +125,10 @@ struct Scene {
     const double* ph_dircol;  // [n_photon][6] leaf order
     const FogD* fogs;
     const double* fog_grid;
+    const TexD* texs;
+    const unsigned char* tex_pixels;
+    const double* tex_lut;    // [256] pow(k / 255.0, 1.0 / (1.0 / GAMMA)) as the host libm computes it = imageTexture::get's gamma()
+    int32_t n_tex;            // > 0: the scene has a non-constant texture (kernels instantiated with GI_FEAT_TEX)
     const HaltonDim* hdims;   // [256]
     const uint16_t* htable;
     int32_t n_node, n_tri, n_light, n_pnode, n_photon;
@@ -433,7 +445,53 @@ GI_HD bool tri_hit(const Tri& g, const Ray& ray, double& u, double& v, double& t
     return true;
 }
 
-struct HitRec { V3 pos; double u, v; int32_t tri; };
+struct HitRec { V3 pos; double u, v; int32_t tri; double tu, tv; };   // u, v barycentric; tu, tv = the reference's `uv` (GI_FEAT_TEX only)
+
+// ------------------------------------------------------------------------------------------------ textures (include/material.h:10-81)
+GI_HD const unsigned char* tex_pixel(const Scene& S, const TexD& x, double tu, double tv)   // image.pixelColor(...), include/material.h:65
+{
+    const int px = abs((int)(tu * x.w * x.tile_u) % x.w);
+    const int py = x.h - abs((int)(tv * x.h * x.tile_v) % x.h) - 1;
+    return S.tex_pixels + x.pix + ((size_t)py * x.w + px) * 4;
+}
+GI_HD V3 tex_get(const Scene& S, int32_t t, V3 constant, double tu, double tv)   // texture::get
+{
+    if (t < 0) return constant;
+    const TexD& x = S.texs[t];
+    if (x.kind == 0) return ld3(x.a);
+    if (x.kind == 1) {
+        const int tiles = (int)x.tiles;
+        if (((int)(tu * tiles) % 2 == 0) ^ ((int)(tv * tiles) % 2 == 0)) return ld3(x.a);
+        return ld3(x.b);
+    }
+    const unsigned char* px = tex_pixel(S, x, tu, tv);
+    return v3(S.tex_lut[px[0]], S.tex_lut[px[1]], S.tex_lut[px[2]]);
+}
+GI_HD double tex_alpha(const Scene& S, int32_t t, double tu, double tv)   // texture::getAlpha
+{
+    if (t < 0) return 1;
+    const TexD& x = S.texs[t];
+    if (x.kind != 2 || !x.has_alpha) return 1;
+    return tex_pixel(S, x, tu, tv)[3] / 255.0;
+}
+// the reference's `uv` after a successful Entity::intersect: interpolated texCoords of a smooth triangle (include/entities.h:480-482),
+// asin / atan2 of a sphere (include/entities.h:93-96); a flat-shaded triangle leaves the caller's variable as it was
+template <class Tri>
+GI_HD void ent_uv(const Scene& S, const Tri& g, uint32_t flags, int32_t ti, double u, double v, V3 hp, double& tu, double& tv)
+{
+    if (flags & 4u) {
+        const V3 d = (ld3(g.p0) - hp) / g.e1[0];
+        tv = .5 + asin(d.y) / GI_PI;
+        tu = .5 + atan2(d.z, d.x) / (2 * GI_PI);
+    } else if (flags & 1u) {
+        const TriShade& sh = S.shade[ti];
+        const double w = (1 - u - v);
+        tu = w * sh.t0[0] + u * sh.t1[0] + v * sh.t2[0];
+        tv = w * sh.t0[1] + u * sh.t1[1] + v * sh.t2[1];
+    }
+}
+// Material::getAlpha = opacity * diffuse->getAlpha(uv), include/material.h:90-93
+GI_HD double mat_alpha(const Scene& S, const Mat& m, double tu, double tv) { return m.opacity * tex_alpha(S, m.dtex, tu, tv); }
 
 // Entity::intersect for the two kinds on this path: triangle (include/entities.h:443-490, barycentric u, v) and analytic sphere
 // (include/entities.h:60-101).  hp = hit point.
@@ -589,6 +647,7 @@ GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rn
     const WRay wr = wray_make(ray);
     bool intersected = false;
     double best_d2 = 0;
+    double cu = 0, cv = 0;   // the reference's `glm::dvec2 uv` of trace(): written by every successful intersect of a smooth triangle or sphere
     WWalk k;
     if (!wwalk_begin(S, W, k, ray, wr, 0.0, INFINITY)) return false;
     for (;;) {
@@ -601,13 +660,16 @@ GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rn
             double u, v;
             V3 hp;
             if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return;
+            if (FEAT & GI_FEAT_TEX) ent_uv(S, g, g.matflags, ti, u, v, hp, cu, cv);
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 3];
-                if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) return;
+                const double alpha = (FEAT & GI_FEAT_TEX) ? mat_alpha(S, m, cu, cv) : m.opacity * 1.0;
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return;
             }
             double d2 = len2(hp - ray.o);
             if (!intersected || d2 < best_d2) {
                 best.pos = hp; best.u = u; best.v = v; best.tri = ti;
+                if (FEAT & GI_FEAT_TEX) { best.tu = cu; best.tv = cv; }
                 best_d2 = d2;
                 intersected = true;
                 double lmin[3], lmax[3];
@@ -644,7 +706,9 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
                 if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) continue;
                 if (!(g.matflags & 2u)) {
                     const Mat& m = S.mats[g.matflags >> 3];
-                    if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                    double alpha = m.opacity * 1.0;
+                    if (FEAT & GI_FEAT_TEX) { double cu = 0, cv = 0; ent_uv(S, g, g.matflags, ti, u, v, hp, cu, cv); alpha = mat_alpha(S, m, cu, cv); }
+                    if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) continue;
                 }
                 double ts = len2(hp - ray.o);
                 if ((ts < mt) && (ts > 0)) return false;
@@ -674,6 +738,7 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
     const int oct = dir_octant(ray);
     bool intersected = false;
     double best_d2 = 0;
+    double cu = 0, cv = 0;
     int32_t node = 0;
     if (c) c->traces++;
     for (;;) {
@@ -702,13 +767,16 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
             V3 hp;
             if (c) c->tri++;
             if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return;
+            if (FEAT & GI_FEAT_TEX) ent_uv(S, g, g.matflags, ti, u, v, hp, cu, cv);
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 3];
-                if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) return;
+                const double alpha = (FEAT & GI_FEAT_TEX) ? mat_alpha(S, m, cu, cv) : m.opacity * 1.0;
+                if (!(rng_draw(rng, alpha_purpose, (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < alpha || m.ior != 1)) return;
             }
             double d2 = len2(hp - ray.o);
             if (!intersected || d2 < best_d2) {
                 best.pos = hp; best.u = u; best.v = v; best.tri = ti;
+                if (FEAT & GI_FEAT_TEX) { best.tu = cu; best.tv = cv; }
                 best_d2 = d2;
                 intersected = true;
                 if (box_contains(lmin, lmax, hp)) term = true;
@@ -727,14 +795,15 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
 }
 GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
+    best.tu = 0; best.tv = 0;
     if (S.wnodes && !c) {   // the work counters count the reference's per-node box tests: counted runs take the per-node walk
         GlobalWide W;
         W.g = S.wnodes;
-        return trace_nodes<3>(S, W, ray, rng, alpha_purpose, best, nullptr);
+        return S.n_tex > 0 ? trace_nodes<7>(S, W, ray, rng, alpha_purpose, best, nullptr) : trace_nodes<3>(S, W, ray, rng, alpha_purpose, best, nullptr);
     }
     GlobalNodes N;
     N.g = S.tnodes;
-    return trace_nodes<3>(S, N, ray, rng, alpha_purpose, best, c);
+    return S.n_tex > 0 ? trace_nodes<7>(S, N, ray, rng, alpha_purpose, best, c) : trace_nodes<3>(S, N, ray, rng, alpha_purpose, best, c);
 }
 
 // RayTracer::visible: any accepted hit with 0 < |hit-o|^2 < mt among the entities of every leaf the segment touches.
@@ -770,7 +839,9 @@ GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double 
             if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) continue;
             if (!(g.matflags & 2u)) {
                 const Mat& m = S.mats[g.matflags >> 3];
-                if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1)) continue;
+                double alpha = m.opacity * 1.0;
+                if (FEAT & GI_FEAT_TEX) { double cu = 0, cv = 0; ent_uv(S, g, g.matflags, ti, u, v, hp, cu, cv); alpha = mat_alpha(S, m, cu, cv); }
+                if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)N.leaf_id(leaf), (uint32_t)ti) < alpha || m.ior != 1)) continue;
             }
             double ts = len2(hp - ray.o);
             if ((ts < mt) && (ts > 0)) return false;
@@ -791,11 +862,11 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
     if (S.wnodes && !c) {
         GlobalWide W;
         W.g = S.wnodes;
-        return visible_nodes<3>(S, W, ray, mt, rng, light_index, nullptr);
+        return S.n_tex > 0 ? visible_nodes<7>(S, W, ray, mt, rng, light_index, nullptr) : visible_nodes<3>(S, W, ray, mt, rng, light_index, nullptr);
     }
     GlobalNodes N;
     N.g = S.tnodes;
-    return visible_nodes<3>(S, N, ray, mt, rng, light_index, c);
+    return S.n_tex > 0 ? visible_nodes<7>(S, N, ray, mt, rng, light_index, c) : visible_nodes<3>(S, N, ray, mt, rng, light_index, c);
 }
 
 // ------------------------------------------------------------------------------------------------ photon gather
@@ -983,11 +1054,11 @@ GI_HD V3 gather(const Scene& S, V3 pos, V3 dir, float* heap_mem, int heap_stride
 
 // ------------------------------------------------------------------------------------------------ shading
 // RayTracer::rayType, include/raytracer.h:481-506
-GI_HD int ray_type(const Mat& m, const Ray& ray, V3 norm, const Rng& rng)
+GI_HD int ray_type(const Mat& m, double tex_a, const Ray& ray, V3 norm, const Rng& rng)
 {
     int type = 2;
     if (m.roughness < .001) type = 0;
-    double opacity = 1.0 * m.opacity;
+    double opacity = tex_a * m.opacity;   // diffuse->getAlpha(minUV) * opacity, include/raytracer.h:486
     if (opacity < 1.0) {  // drand() in [0,1) can exceed the opacity only then
         if (rng_draw(rng, P_TYPE_OPACITY) > opacity) {
             double r0 = pow((1 - m.ior) / (1 + m.ior), 2.0);
@@ -999,13 +1070,13 @@ GI_HD int ray_type(const Mat& m, const Ray& ray, V3 norm, const Rng& rng)
     return type;
 }
 // RayTracer::secondaryRay, include/raytracer.h:321-379
-GI_HD void secondary_ray(const Ray& ray, const Mat& m, V3& norm, double sx, double sy, V3& refDir, V3& f, double& roughness, V3& contrib, double& offset, const Rng& rng)
+GI_HD void secondary_ray(const Ray& ray, const Mat& m, V3 color, double tex_a, V3& norm, double sx, double sy, V3& refDir, V3& f, double& roughness, V3& contrib, double& offset, const Rng& rng)
 {
+    // color = diffuse->get(UV), tex_a = diffuse->getAlpha(UV) (1 and the constant colour without GI_FEAT_TEX)
     bool backface = false;
     if (dot(norm, ray.d) > 0) { norm = norm * -1.0; backface = true; }
-    V3 color = ld3(m.diffuse);
     roughness = m.roughness;
-    int type = ray_type(m, ray, norm, rng);
+    int type = ray_type(m, tex_a, ray, norm, rng);
     if (type == 1) {
         refDir = backface ? refr(ray.d, norm, m.ior) : refr(ray.d, norm, 1.0 / m.ior);
         offset *= -1;
@@ -1075,6 +1146,7 @@ GI_HD bool stage_trace_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_
     }
     p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
     p.hu = h.u; p.hv = h.v; p.htri = h.tri;
+    if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
     return true;
 }
 GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
@@ -1082,11 +1154,11 @@ GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     if (S.wnodes && !c) {
         GlobalWide W;
         W.g = S.wnodes;
-        return stage_trace_nodes<3>(S, W, p, seed, nullptr);
+        return S.n_tex > 0 ? stage_trace_nodes<7>(S, W, p, seed, nullptr) : stage_trace_nodes<3>(S, W, p, seed, nullptr);
     }
     GlobalNodes N;
     N.g = S.tnodes;
-    return stage_trace_nodes<3>(S, N, p, seed, c);
+    return S.n_tex > 0 ? stage_trace_nodes<7>(S, N, p, seed, c) : stage_trace_nodes<3>(S, N, p, seed, c);
 }
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
 template <int FEAT, class Nodes>
@@ -1103,10 +1175,17 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     float sy = halton_sample(S, 3 + 2 * depth, p.stream);
     const Mat& m = S.mats[S.tris[h.tri].mat];
     V3 norm = shading_normal(S, h);
-    V3 color = ld3(m.diffuse);
+    V3 color = ld3(m.diffuse), emissive = ld3(m.emissive);
+    double tex_a = 1;
+    if (FEAT & GI_FEAT_TEX) {   // diffuse->get(minUV), emissive->get(minUV), diffuse->getAlpha(minUV): include/raytracer.h:200,269,486
+        const double tu = p.gdir[0], tv = p.gdir[1];
+        color = tex_get(S, m.dtex, color, tu, tv);
+        emissive = tex_get(S, m.etex, emissive, tu, tv);
+        tex_a = tex_alpha(S, m.dtex, tu, tv);
+    }
     V3 refDir, f = v3(1, 1, 1), i = v3(0, 0, 0), contrib = ld3(p.contrib);
     double roughness, offset = GI_SHADOW_BIAS;
-    secondary_ray(ray, m, norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
+    secondary_ray(ray, m, color, tex_a, norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
     if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:209-228: the segment may end in the medium instead
         double tmin = 0, tmx = length(h.pos - ray.o);
         if (atmosphere_bounds(S, ray, tmin, tmx)) {
@@ -1147,7 +1226,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     double q = comp_max(contrib);
     if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
         f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
-        L = L + T * (color * i + ld3(m.emissive));
+        L = L + T * (color * i + emissive);
         p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
         int flags = 0;
         if (depth <= 10 && S.n_pnode > 0) {   // caustic = depth <= 10 ? samplePhotons(minHit, refDir, 32) : 0, include/raytracer.h:258
@@ -1174,11 +1253,11 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     if (S.wnodes && !c) {
         GlobalWide W;
         W.g = S.wnodes;
-        return stage_shade_nodes<3>(S, W, p, seed, nullptr);
+        return S.n_tex > 0 ? stage_shade_nodes<7>(S, W, p, seed, nullptr) : stage_shade_nodes<3>(S, W, p, seed, nullptr);
     }
     GlobalNodes N;
     N.g = S.tnodes;
-    return stage_shade_nodes<3>(S, N, p, seed, c);
+    return S.n_tex > 0 ? stage_shade_nodes<7>(S, N, p, seed, c) : stage_shade_nodes<3>(S, N, p, seed, c);
 }
 // stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
 GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride)
@@ -1287,7 +1366,10 @@ GI_HD bool emit_photon(const Scene& S, int32_t i, int32_t li, int32_t count, int
                 double offset = GI_SHADOW_BIAS;
                 double e13 = rng_draw(rng, P_PH_SEC_V);
                 double e5 = rng_draw(rng, P_PH_SEC_U);
-                secondary_ray(r, m, norm, fmod(e5 + 5 * i, 1.0), fmod(e13 + 13 * i, 1.0), refDir, f, roughness, contrib, offset, rng);
+                V3 pcolor = ld3(m.diffuse);
+                double tex_a = 1;
+                if (S.n_tex > 0) { pcolor = tex_get(S, m.dtex, pcolor, h.tu, h.tv); tex_a = tex_alpha(S, m.dtex, h.tu, h.tv); }
+                secondary_ray(r, m, pcolor, tex_a, norm, fmod(e5 + 5 * i, 1.0), fmod(e13 + 13 * i, 1.0), refDir, f, roughness, contrib, offset, rng);
                 if (S.n_fog > 0) {   // include/raytracer.h:658-675
                     double tmin = 0, tmx = length(hit - r.o);
                     if (atmosphere_bounds(S, r, tmin, tmx)) {

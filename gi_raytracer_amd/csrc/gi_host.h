@@ -21,7 +21,7 @@ void gih_scene_destroy(gih_scene*);
 const char* gih_last_error(const gih_scene*);
 
 /* replaces loadScene + loadOBJ (include/sceneLoader.cpp:12-185, include/meshLoader.cpp:18-99): same keyword set and the
- * same word-wise tokenising (keywords colorTex, mat, multiMat, mesh, sphere, box, light, heightFog, photons, samples, ambient, camera);
+ * same word-wise tokenising (keywords colorTex, checkerboardTex, imTex, mat, multiMat, mesh, sphere, box, light, heightFog, photons, samples, ambient, camera);
  * vertices, normals and uvs are rounded to float as the reference's loader does.  A `mat` line
  * without its 5th number gets IOR 1.0 (the reference leaves it uninitialised).  Missing mesh files are skipped.
  * Returns 0, or -1 when the .scn itself cannot be opened.                                                            */

@@ -741,6 +741,9 @@ struct gi_ctx {
     Scene S{};
     DevBuf<TNode> d_tnodes;
     DevBuf<WNode> d_wnodes;
+    DevBuf<TexD> d_texs;
+    DevBuf<unsigned char> d_tex_pixels;
+    DevBuf<double> d_tex_lut;
     DevBuf<int32_t> d_wleaf_id;
     bool wide_enabled = true;         // gi_set_wide_nodes
     DevBuf<int32_t> d_refs;
@@ -880,6 +883,9 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_tnodes.upload(H.tnodes));
     HIP_TRY(c, c->d_wnodes.upload(H.wnodes));
     HIP_TRY(c, c->d_wleaf_id.upload(H.wleaf_id));
+    HIP_TRY(c, c->d_texs.upload(H.texs));
+    HIP_TRY(c, c->d_tex_pixels.upload(H.tex_pixels));
+    HIP_TRY(c, c->d_tex_lut.upload(H.tex_lut));
     HIP_TRY(c, c->d_refs.upload(H.refs));
     HIP_TRY(c, c->d_leaf_tris.upload(H.leaf_tris));
     HIP_TRY(c, c->d_tris.upload(H.tris));
@@ -895,6 +901,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     S.n_wnode = (int32_t)H.wnodes.size();
     S.wnodes = (c->wide_enabled && S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
     S.wleaf_id = c->d_wleaf_id.p;
+    S.texs = c->d_texs.p; S.tex_pixels = c->d_tex_pixels.p; S.tex_lut = c->d_tex_lut.p; S.n_tex = H.n_tex();
     S.has_spheres = 0;
     S.fogs = c->d_fogs.p; S.fog_grid = c->d_fog_grid.p; S.n_fog = H.n_fog();
     for (const TriGeom& g : H.tris) if (g.flags & 4u) S.has_spheres = 1;
@@ -1084,8 +1091,8 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0, g_finish = 0;
     const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
     if (!g_trace) {
-        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<3, 1>, lds_nodes, GI_TRACE_BLOCK);
-        g_shade = grid_for(c, (const void*)k_st_shade<3, 1>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<3, 1>);
+        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<7, 1>, lds_nodes, GI_TRACE_BLOCK);
+        g_shade = grid_for(c, (const void*)k_st_shade<7, 1>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<7, 1>);
     }
     hipStream_t st = c->stream;
     const bool wide = c->S.wnodes != nullptr;
@@ -1127,7 +1134,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             uint32_t* qcont_out = q_cont[ping];
             const uint32_t* qcont_in = q_cont[ping ^ 1];
             if (next >= sample_end && n_new == 0 && n_cont <= c->finish_threshold) {
-                const bool sphf = c->S.has_spheres != 0, fogf = c->S.n_fog > 0;
+                const bool sphf = c->S.has_spheres != 0, fogf = c->S.n_fog > 0, texf = c->S.n_tex > 0;
                 if (c->d_fin_cnt.n < 16) HIP_TRY(c, c->d_fin_cnt.alloc(16));
                 HIP_TRY(c, hipMemsetAsync(c->d_fin_cnt.p, 0, 16 * sizeof(unsigned int), st));
                 const uint32_t* fq_in = qcont_in;
@@ -1137,7 +1144,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
                     const int lanes = c->finish_plan[k].first, vertices = k + 1 == n_stage ? GI_MAX_DEPTH + 1 : c->finish_plan[k].second;
                     const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
                     stage_begin(c, STG_FINISH);
-                    hipLaunchKernelGGL(wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
+                    hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1> : k_st_finish<7, 0>) : wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
                                        fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, c->d_lbuf.p);
                     stage_end(c);
                     launches++;
@@ -1147,10 +1154,10 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             }
             HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
             uint32_t* qfree_out = q_free[ping];
-            const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0;
-            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+            const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0, tex = c->S.n_tex > 0;
+            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
                                q_shade, qfree_out, c->d_lbuf.p); stage_end(c);
-            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
+            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(tex ? (wide ? k_st_shade<7, 1> : k_st_shade<7, 0>) : wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
                                qfree_out, c->d_lbuf.p); stage_end(c);
             launches += 2;
             HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));

@@ -31,6 +31,10 @@ struct HostScene {
     std::vector<LightD> lights;
     std::vector<FogD> fogs;
     std::vector<double> fog_grid;
+    std::vector<TexD> texs;           // only when the scene has a non-constant texture (n_tex() > 0)
+    std::vector<unsigned char> tex_pixels;
+    std::vector<double> tex_lut;
+    int32_t n_tex() const { return (int32_t)texs.size(); }
     int32_t n_node = 0, n_tri = 0, n_light = 0;
     double ambient[3] = {0, 0, 0};
     int32_t n_fog() const { return (fogs.size() == 1 && fogs[0].grid_n == 0) ? 0 : (int32_t)fogs.size(); }
@@ -120,6 +124,18 @@ inline bool validate_scene(const gi_scene_desc* d, std::string& err)
         if (d->ent_kind && d->ent_kind[i] != 0 && d->ent_kind[i] != 1) { err = "scene: unknown entity kind"; return false; }
     }
     if (d->n_mat >= (1 << 28)) { err = "scene: too many materials"; return false; }
+    if (d->n_tex < 0 || (d->n_tex > 0 && (!d->tex_kind || !d->tex_param || !d->mat_tex))) { err = "scene: null texture tables"; return false; }
+    for (int t = 0; t < d->n_tex; t++) {
+        const double* q = d->tex_param + (size_t)t * 8;
+        if (d->tex_kind[t] < 0 || d->tex_kind[t] > 2) { err = "scene: unknown texture kind"; return false; }
+        if (d->tex_kind[t] == 2) {
+            const double w = q[2], h = q[3], off = q[5];
+            if (!(w >= 1 && h >= 1 && w <= 32768 && h <= 32768 && off >= 0) || !d->tex_pixels || off + w * h * 4 > (double)d->n_tex_pixel_bytes) { err = "scene: image texture outside the pixel table"; return false; }
+        }
+    }
+    if (d->n_tex > 0)
+        for (int m = 0; m < d->n_mat * 2; m++)
+            if (d->mat_tex[m] < -1 || d->mat_tex[m] >= d->n_tex) { err = "scene: material texture index out of range"; return false; }
     const int nref = d->node_ent_off[d->n_node];
     if (d->node_ent_off[0] != 0 || nref < 0 || (nref && !d->node_ent_idx)) { err = "scene: bad leaf reference table"; return false; }
     for (int n = 0; n < d->n_node; n++) {
@@ -268,7 +284,9 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         const double* m = d->mats + (size_t)g.mat * 9;
         const bool sphere = d->ent_kind && d->ent_kind[i] == 1;
         const bool smooth = !sphere && len2(ld3(N)) > 0 && len2(ld3(N + 3)) > 0 && len2(ld3(N + 6)) > 0;   // include/entities.h:478
-        const bool always = (m[1] * 1.0 >= 1.0) || (m[2] != 1);                                  // include/raytracer.h:455
+        bool tex_has_alpha = false;   // Material::getAlpha = opacity * diffuse->getAlpha(uv): below 1 wherever an image's alpha channel says so
+        if (d->n_tex > 0) { const int dt = d->mat_tex[(size_t)g.mat * 2]; tex_has_alpha = dt >= 0 && d->tex_kind[dt] == 2 && d->tex_param[(size_t)dt * 8 + 4] != 0; }
+        const bool always = (!tex_has_alpha && m[1] * 1.0 >= 1.0) || (m[2] != 1);                // include/raytracer.h:455
         g.flags = (smooth ? 1u : 0u) | (always ? 2u : 0u) | (sphere ? 4u : 0u);
         if (sphere) { g.e1[0] = P[3]; g.e1[1] = 0; g.e1[2] = 0; g.e2[0] = 0; g.e2[1] = 0; g.e2[2] = 0; }   // centre in p0, radius in e1[0]
         TriShade& s = H.shade[i];
@@ -276,6 +294,7 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         V3 fn = sphere ? v3(0, 0, 0) : normalize(cross((p1 - p0), (p2 - p0)));                   // include/entities.h:339
         s.fnorm[0] = fn.x; s.fnorm[1] = fn.y; s.fnorm[2] = fn.z;
         if (sphere) { s.n0[0] = P[0]; s.n0[1] = P[1]; s.n0[2] = P[2]; }                         // centre, for the shading normal
+        for (int k = 0; k < 2; k++) { s.t0[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + k] : 0; s.t1[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + 2 + k] : 0; s.t2[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + 4 + k] : 0; }
     }
     H.leaf_tris.resize(H.refs.size());
     for (size_t r = 0; r < H.refs.size(); r++) {
@@ -291,12 +310,37 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         const double* m = d->mats + (size_t)i * 9;
         H.mats[i].roughness = m[0]; H.mats[i].opacity = m[1]; H.mats[i].ior = m[2];
         for (int k = 0; k < 3; k++) { H.mats[i].diffuse[k] = m[3 + k]; H.mats[i].emissive[k] = m[6 + k]; }
+        H.mats[i].dtex = d->n_tex > 0 ? d->mat_tex[(size_t)i * 2] : -1;
+        H.mats[i].etex = d->n_tex > 0 ? d->mat_tex[(size_t)i * 2 + 1] : -1;
     }
     H.lights.resize((size_t)d->n_light);
     for (int i = 0; i < d->n_light; i++) {
         const double* l = d->lights + (size_t)i * 11;
         for (int k = 0; k < 3; k++) { H.lights[i].pos[k] = l[k]; H.lights[i].col[k] = l[3 + k]; H.lights[i].dir[k] = l[7 + k]; }
         H.lights[i].rad = l[6]; H.lights[i].angle = l[10];
+    }
+    // textures: device records only when something is not a constant colour (then the kernels take the GI_FEAT_TEX instances)
+    H.texs.clear(); H.tex_pixels.clear(); H.tex_lut.clear();
+    bool textured = false;
+    for (int t = 0; t < d->n_tex; t++) if (d->tex_kind[t] != 0) textured = true;
+    if (textured) {
+        H.texs.resize((size_t)d->n_tex);
+        for (int t = 0; t < d->n_tex; t++) {
+            const double* q = d->tex_param + (size_t)t * 8;
+            TexD& x = H.texs[t];
+            memset(&x, 0, sizeof x);
+            x.kind = d->tex_kind[t];
+            if (x.kind == 2) { x.tile_u = q[0]; x.tile_v = q[1]; x.w = (int32_t)q[2]; x.h = (int32_t)q[3]; x.has_alpha = q[4] != 0; x.pix = (unsigned long long)q[5]; }
+            else { for (int k = 0; k < 3; k++) { x.a[k] = q[k]; x.b[k] = q[3 + k]; } x.tiles = q[6]; }
+        }
+        if (d->n_tex_pixel_bytes > 0) H.tex_pixels.assign(d->tex_pixels, d->tex_pixels + d->n_tex_pixel_bytes);
+        // imageTexture::get: gamma({p/255}, 1.0/GAMMA) = pow(p / 255.0, 1.0 / (1.0 / 2.2)) (include/material.h:67, include/util.h:94-97),
+        // evaluated once per 8-bit value with the host's libm -- the library the reference itself calls
+        H.tex_lut.resize(256);
+        const double g = 1.0 / 2.2;
+        for (int k = 0; k < 256; k++) H.tex_lut[k] = std::pow(k / 255.0, 1.0 / g);
+    } else {
+        for (Mat& m : H.mats) { m.dtex = -1; m.etex = -1; }
     }
     H.fogs.clear(); H.fog_grid.clear();
     if (d->n_fog < 0 || (d->n_fog > 0 && (!d->fog || !d->fog_grid_off || !d->fog_grid))) { err = "scene: bad atmosphere tables"; return false; }

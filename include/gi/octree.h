@@ -4,7 +4,9 @@
 // RayTracer uploads to the GPU.  The per-ray queries (intersect / intersectSorted) are gone from the host: they are the
 // traversal inside the HIP kernels.
 #pragma once
+#include <map>
 #include <stdexcept>
+#include <string>
 #include <vector>
 #include "../../gi_raytracer_amd/csrc/gi_host.h"
 #include "atmosphere.h"
@@ -33,11 +35,21 @@ class Octree {
         if (_loaded) { gih_scene_destroy(fresh); fresh = nullptr; }   // filled by loadScene(): keep that scene
         gih_scene* s = fresh ? fresh : _h;
         if (fresh) {
+            std::map<const texture*, int> tex_id;   // each texture object registered once (include/material.h:10-81)
+            std::map<std::vector<double>, int> mat_id;
+            auto tex_of = [&](const texture* t) {
+                auto it = tex_id.find(t);
+                if (it != tex_id.end()) return it->second;
+                const int id = t->gi_register(s);
+                if (id < 0) { std::string e = gih_last_error(s); gih_scene_destroy(fresh); throw std::runtime_error("Octree::rebuild: " + e); }
+                tex_id[t] = id;
+                return id;
+            };
             for (Entity* e : _entities) {
-                gi::dvec2 uv0(0, 0);
-                const gi::dvec3 d = e->material.diffuse->get(uv0), em = e->material.emissive->get(uv0);
-                const double m[9] = {e->material.roughness, e->material.opacity, e->material.IOR, d.x, d.y, d.z, em.x, em.y, em.z};
-                const int mi = gih_add_material(s, m);
+                const int dt = tex_of(e->material.diffuse), et = tex_of(e->material.emissive);
+                const std::vector<double> key = {(double)dt, (double)et, e->material.roughness, e->material.opacity, e->material.IOR};
+                auto mit = mat_id.find(key);
+                const int mi = mit != mat_id.end() ? mit->second : (mat_id[key] = gih_add_material_tex(s, dt, et, e->material.roughness, e->material.opacity, e->material.IOR));
                 if (sphere* sp = dynamic_cast<sphere*>(e)) {
                     const double c[3] = {sp->pos.x, sp->pos.y, sp->pos.z};
                     gih_add_sphere(s, c, sp->rad, mi);

@@ -26,6 +26,19 @@ int main(int argc, char** argv)
     quad->push_back(new triangle(vertex(gi::dvec3(0, 0, 0)), vertex(gi::dvec3(1, 0, 0)), vertex(gi::dvec3(0, 0, 1)), mat));
     quad->push_back(new triangle(vertex(gi::dvec3(1, 0, 0)), vertex(gi::dvec3(1, 0, 1)), vertex(gi::dvec3(0, 0, 1)), mat));
     quad->push_back(new sphere(gi::dvec3(0.5, 0.3, 0.5), 0.3, mat));
+    // textured materials as the scene loader builds them (sceneLoader.cpp:47-64): checkerboard and image file
+    checkerboard cb(4, gi::dvec3(1, 1, 1), gi::dvec3(0, 0, 1));
+    Material cbm(&cb, &black, 1, 1);
+    quad->push_back(new triangle(vertex(gi::dvec3(0, 1, 0), gi::dvec3(0, 1, 0), gi::dvec2(0, 0)), vertex(gi::dvec3(1, 1, 0), gi::dvec3(0, 1, 0), gi::dvec2(1, 0)),
+                                 vertex(gi::dvec3(0, 1, 1), gi::dvec3(0, 1, 0), gi::dvec2(0, 1)), cbm));
+    if (argc > 3) {
+        imageTexture* im = new imageTexture(argv[3], gi::dvec2(2, 1));
+        gi::dvec2 uv(0.3, 0.4);
+        gi::dvec3 px = im->get(uv);
+        printf("image %dx%d alpha %d get(0.3,0.4) %.12f %.12f %.12f a %.6f\n", im->width, im->height, (int)im->has_alpha, px.x, px.y, px.z, im->getAlpha(uv));
+        Material imm(im, &black, 1, 1);
+        quad->push_back(new sphere(gi::dvec3(0.2, 0.3, 0.2), 0.1, imm));
+    }
     quad->push_back(new HeightFog(gi::dvec3(0.5, 0.5, 0.5), gi::dvec3(1, 1, 1), gi::dvec3(1, 1, 1), 2, .5, 2));
     quad->push_back(new Light(gi::dvec3(0, 5, 0), gi::dvec3(0, 0, 0), gi::dvec3(4, 4, 4), .05));
     quad->rebuild();

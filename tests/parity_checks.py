@@ -9,7 +9,7 @@ import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCN = {"test_scene": "scenes/test_scene/test.scn", "cornell": "scenes/cornell/test.scn", "caustics": "scenes/caustics/caustics.scn",
-       "teapot": "scenes/cornell/teapot.scn", "textures": "scenes/textures/tex.scn", "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn", "fog": "scenes/fog/fog.scn"}
+       "teapot": "scenes/cornell/teapot.scn", "textures": "scenes/textures/tex.scn", "textures_opaque": "scenes/textures/tex_opaque.scn", "cornell_tex": "scenes/textures/cornell_tex.scn", "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn", "fog": "scenes/fog/fog.scn"}
 
 # float tolerance of the path (north_star: pixel RMSE < 1e-4 on linear radiance); measured values are ~1e-16
 RMSE_TOL = 1e-4
@@ -77,7 +77,7 @@ def check_emission(rt, scene, n):
     return o, ph
 
 
-def check_render(rt, scene, w, h, spp, photons, adaptive=False):
+def check_render(rt, scene, w, h, spp, photons, adaptive=False, tol=RMSE_TOL, spp_mismatch=0.0):
     o = oracle_for(scene)
     if photons > 0 and scene.desc().n_light > 0:
         ph, _ = rt.tracePhotons(photons)
@@ -86,13 +86,13 @@ def check_render(rt, scene, w, h, spp, photons, adaptive=False):
     if adaptive:
         img, nspp = rt.run(w, h, min_samples=spp, max_samples=4 * spp, noise_thresh=0.0015, want_spp=True)
         ref = o.render(w, h, spp, 4 * spp, 0.0015)
-        assert np.array_equal(nspp, ref["spp"])                  # per-pixel sample counts are integer work: exact
+        assert (nspp != ref["spp"]).mean() <= spp_mismatch       # per-pixel sample counts are integer work: exact (spp_mismatch = 0)
     else:
         img, nspp = rt.run(w, h, min_samples=spp, max_samples=spp, want_spp=True)
         ref = o.render(w, h, spp)
         assert (nspp == spp).all(), (np.unique(nspp, return_counts=True), float(img.mean()))
     rmse = float(np.sqrt(((img - ref["lin"]) ** 2).mean()))
-    assert rmse < RMSE_TOL, rmse
+    assert rmse < tol, rmse
     return rmse, img, ref["lin"]
 
 
@@ -181,6 +181,9 @@ def check_wide_walk(rt, scene, set_wide):
     rays = adversarial_rays(scene)
     rs = np.random.RandomState(9)
     q = np.concatenate([rays[:, :3], rays[:, :3] + rays[:, 3:] * (rs.rand(len(rays), 1) * 12 + 0.01)], 1)
+    if (scene.tables()["node_child"][0] < 0).all():
+        assert not set_wide(True)          # the root is a leaf: nothing to walk, the per-node path handles it
+        return
     assert set_wide(True), "the scene's octree was not accepted as exact octants"
     hit_w, ent_w, res_w = rt.trace(rays)
     vis_w = rt.visible(q)

@@ -24,6 +24,23 @@ def test_host_side_of_the_dropin_api():
     assert "quad valid 1" in out
 
 
+def test_dropin_texture_classes_match_the_reference(golden):
+    """checkerboard / imageTexture of include/gi/material.h: the PNG decoded as the reference's QImage saw it, get() / getAlpha() as its
+    texture::get did (fixture scene_textures: tex 2 = cutout_binary.png tiled 2 x 1)."""
+    build()
+    out = subprocess.run([EXE, os.path.join(ROOT, "scenes/caustics/caustics.scn"), "host", os.path.join(ROOT, "scenes/textures/cutout_binary.png")],
+                         check=True, capture_output=True, text=True).stdout
+    m = re.search(r"image (\d+)x(\d+) alpha (\d) get\(0.3,0.4\) ([0-9.eE+-]+) ([0-9.eE+-]+) ([0-9.eE+-]+) a ([0-9.eE+-]+)", out)
+    assert m, out
+    fx = golden("scene_textures")
+    t = int(np.flatnonzero((fx["tex_kind"] == 2) & (fx["tex_param"][:, 4] == 1))[0])
+    assert (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (int(fx["tex_param"][t, 2]), int(fx["tex_param"][t, 3]), 1)
+    import oracle_lib as ol
+    ref = ol.Oracle.from_fixture(fx).tex_eval(t, [[0.3, 0.4]])[0]
+    got = np.array([float(m.group(k)) for k in (4, 5, 6, 7)])
+    assert np.allclose(got, ref, rtol=0, atol=1e-11) and "quad valid 1" in out
+
+
 @pytest.mark.gpu
 def test_dropin_render_matches_python_path():
     import gi_raytracer_amd as gi

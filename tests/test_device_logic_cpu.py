@@ -8,7 +8,7 @@ import emul_lib as el
 import parity_checks as pc
 
 
-@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque"])
+@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque", "textures_opaque"])
 def setup(request, golden):
     scene = pc.load_scene(request.param)
     return request.param, scene, el.EmulRayTracer().setScene(scene), golden("scene_" + request.param.replace("_opaque", ""))
@@ -82,6 +82,18 @@ def test_render_with_stochastic_alpha_and_glass_matches_oracle():
     rt = el.EmulRayTracer().setScene(scene)
     rmse, img, ref = pc.check_render(rt, scene, 40, 30, 6, 1500)
     assert rmse < 1e-12 and img.mean() > 0.01
+
+
+def test_textured_scene_render_and_emission_match_oracle():
+    """scenes/textures/tex.scn: checkerboard and PNG textures on meshes and spheres as diffuse and emissive colour, an alpha channel
+    and a 0.7 opacity in the stochastic alpha test of trace / visible / rayType (include/material.h:32-93)."""
+    scene = pc.load_scene("textures")
+    rt = el.EmulRayTracer().setScene(scene)
+    pc.check_emission(rt, scene, 600)
+    rmse, img, ref = pc.check_render(rt, scene, 40, 30, 6, 1500)
+    assert rmse < 1e-12 and img.mean() > 0.01
+    for mode in ("adaptive",):
+        pc.check_render(rt, scene, 32, 24, 4, 1500, adaptive=True)
 
 
 def test_height_fog_render_and_emission_match_oracle():
