@@ -293,6 +293,27 @@ class Scene:
                 "node_idx": _np_from(d.node_idx, (int(nref),), np.int32)}
 
 
+def save_pfm(path, lin):
+    """Linear radiance [h][w][3] as a little-endian PFM (rows bottom to top)."""
+    a = np.ascontiguousarray(lin, np.float32)
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (a.shape[1], a.shape[0]))
+        f.write(a[::-1].astype("<f4").tobytes())
+
+
+def to_rgb8(lin):
+    """The reference's display transform: gamma 2.2, clamp to [0, 1], truncating (int)(255 c) (include/raytracer.h:150-157, image.h:15)."""
+    c = np.clip(np.power(np.maximum(np.asarray(lin, np.float64), 0.0), 1.0 / 2.2), 0.0, 1.0)
+    return (255 * c).astype(np.int32).astype(np.uint8)
+
+
+def save_ppm(path, lin):
+    a = to_rgb8(lin)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+        f.write(a.tobytes())
+
+
 class RayTracer:
     """Device context = the reference's RayTracer for this path (include/raytracer.h:23-735)."""
 

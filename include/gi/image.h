@@ -1,7 +1,9 @@
 // include/gi/image.h -- Qt-free mirror of include/image.h:7-29: RGB888 store with the reference's truncating (int)(255 c);
 // `rgb()` hands the bytes to a QImage (INTEGRATION.md shows the two-line adapter the Viewer needs).
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <vector>
 #include "vec.h"
 struct Image {
@@ -21,7 +23,26 @@ struct Image {
     }
     void clear() { std::fill(_rgb.begin(), _rgb.end(), 0); }
     const uint8_t* rgb() const { return _rgb.data(); }
+    // headless output: binary PPM of the 8-bit frame the Viewer would paint
+    bool save_ppm(const char* path) const
+    {
+        FILE* f = fopen(path, "wb");
+        if (!f) return false;
+        fprintf(f, "P6\n%d %d\n255\n", _w, _h);
+        const bool ok = fwrite(_rgb.data(), 1, _rgb.size(), f) == _rgb.size();
+        return fclose(f) == 0 && ok;
+    }
   private:
     int _w, _h;
     std::vector<uint8_t> _rgb;
 };
+// linear (pre-gamma, unclamped) radiance as a little-endian PFM, rows bottom to top as the format wants them
+inline bool gi_save_pfm(const char* path, const float* lin_rgb, int w, int h)
+{
+    FILE* f = fopen(path, "wb");
+    if (!f) return false;
+    fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
+    bool ok = true;
+    for (int y = h - 1; y >= 0 && ok; y--) ok = fwrite(lin_rgb + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f) == (size_t)w * 3;
+    return fclose(f) == 0 && ok;
+}

@@ -3,6 +3,7 @@
 // otherwise only the host side (loader, Octree::rebuild, API surface, copyability) is exercised.
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include "../../include/gi/raytracer.h"
 #include "../../include/gi/sceneLoader.h"
 
@@ -55,6 +56,7 @@ int main(int argc, char** argv)
         double lin = 0;
         for (float v : copy.linear()) lin += v;
         printf("rendered 64x36: 8-bit sum %.6f linear mean %.9f\n", sum, lin / copy.linear().size());
+        if (argc > 4) printf("saved %d %d\n", (int)img->save_ppm((std::string(argv[4]) + ".ppm").c_str()), (int)gi_save_pfm((std::string(argv[4]) + ".pfm").c_str(), copy.linear().data(), 64, 36));
     }
     return 0;
 }

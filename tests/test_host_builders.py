@@ -70,3 +70,19 @@ def test_bad_inputs_fail_loudly(tmp_path):
     scn.write_text("imTex a.png 1 1\n")
     with pytest.raises(gi.GiError):
         gi.Scene.load(str(scn))                    # image textures are out of scope: refuse instead of guessing
+
+
+def test_pfm_and_ppm_writers(tmp_path):
+    """Headless output: PFM of the linear frame, PPM of the reference's display transform (gamma 2.2, clamp, truncate)."""
+    import gi_raytracer_amd as gi
+    lin = np.random.RandomState(0).rand(5, 7, 3).astype(np.float32) * 1.5
+    gi.save_pfm(str(tmp_path / "a.pfm"), lin)
+    raw = open(tmp_path / "a.pfm", "rb").read()
+    assert raw.startswith(b"PF\n7 5\n-1.0\n")
+    back = np.frombuffer(raw[len(b"PF\n7 5\n-1.0\n"):], "<f4").reshape(5, 7, 3)[::-1]
+    assert np.array_equal(back, lin)
+    gi.save_ppm(str(tmp_path / "a.ppm"), lin)
+    raw = open(tmp_path / "a.ppm", "rb").read()
+    px = np.frombuffer(raw[len(b"P6\n7 5\n255\n"):], np.uint8).reshape(5, 7, 3)
+    want = (255 * np.clip(lin.astype(np.float64) ** (1 / 2.2), 0, 1)).astype(np.int32)
+    assert np.array_equal(px, want) and px.max() == 255
