@@ -6,6 +6,8 @@ energy bounds) -- the oracle would need minutes there.
 Tolerances: integer / index results exact; hit points and normals bit-exact (same IEEE operations, no contraction);
 radiance RMSE < 1e-4 (north_star), measured ~1e-16.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -72,6 +74,19 @@ def test_textured_cornell_scene_wide_and_per_node():
     assert not rt.set_wide_nodes(False)
     b = rt.run(96, 54, min_samples=8, max_samples=8)
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_large_procedural_scene_matches_oracle():
+    """tools/big_scene.py at test size (21 k triangles, 25 k octree nodes, built through the programmatic API): ~85x more inner nodes than
+    the LDS window holds, glass and diffuse blobs, a checkerboard floor.  213 k triangles run as a probe."""
+    import sys
+    sys.path.insert(0, os.path.join(pc.ROOT, "tools"))
+    import big_scene
+    scene = big_scene.build(40, 80, textured=True)
+    rt = gi.RayTracer(0).setScene(scene)
+    assert rt.set_wide_nodes(True)
+    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, tol=1e-3)
+    assert img.mean() > 0.01 and np.median(np.abs(img - ref)) < 1e-12 and (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.02
 
 
 def test_glass_teapot_scene_matches_oracle():
