@@ -415,7 +415,8 @@ class RayTracer:
         rc = self.L.gi_set_wide_nodes(self.h, 1 if on else 0)
         if rc < 0:
             self._check(rc, "set_wide_nodes")
-        return rc == 1
+        self.photon_planes = bool(rc & 2)      # the photon octree's one-record-per-level descent is in use
+        return bool(rc & 1)
 
     def set_pool_slots(self, slots):
         self._check(self.L.gi_set_pool_slots(self.h, int(slots)), "set_pool_slots")

@@ -101,9 +101,11 @@ struct alignas(128) PNode { // 128 B: photon octree node; the 8 children of a no
     double bmin[3], bmax[3];// node box: PhotonMap::Node::getBounds checks contains() at every level
     double mid[3];          // inner nodes: lower corner of child 7 = the split point the reference computes
     int32_t first_child;    // record index of child 0, or -1 for a leaf
-    int32_t nb_off, nb_cnt; // leaves: candidate photon ranges [nb_off, nb_off + nb_cnt) in Scene::pranges
-    int32_t nb_photons;     // leaves: total photons in those ranges (= what PhotonMap::getInRange returns for this leaf)
-    int32_t pad[10];
+    int32_t nb_off;         // leaves: candidate photon ranges [nb_off, nb_off + nb_cnt) in Scene::pranges
+    union {
+        struct { int32_t nb_cnt, nb_photons, pad[10]; } lf;   // leaves: nb_photons = total photons in those ranges (= what getInRange returns here)
+        struct { double lo2[3], hi2[3]; } in;                 // inner nodes: the high-side children span [lo2, hi2] (= [min + .5 d, mid + .5 d],
+    } u;                                                      // include/photonMap.cpp:139-149), child 7 [mid, max], low-side children [min, mid]
 };
 struct PRange { int32_t first, count; };   // photons are stored leaf by leaf in the reference's DFS order
 struct HaltonDim { uint32_t P, n, off; float scale; };
@@ -133,6 +135,7 @@ struct Scene {
     const uint16_t* htable;
     int32_t n_node, n_tri, n_light, n_pnode, n_photon;
     int32_t n_wnode;
+    int32_t pn_planes;        // photon octree: every inner record carries its children's planes (gather_find_leaf)
     int32_t has_spheres;      // 0: triangles only
     int32_t n_fog;
     double ambient[3];
@@ -922,6 +925,25 @@ GI_HD int32_t gather_find_leaf(const Scene& S, V3 pos)
 {
     if (S.n_pnode <= 0) return -1;
     int32_t node = 0;
+    if (S.pn_planes) {
+        // one record per level: the child's box is made of the parent's planes (checked bit for bit against the children's stored boxes
+        // when the map was laid out), so the child's own record is only fetched to go on
+        for (;;) {
+            const PNode& nd = S.pnodes[node];
+            if (nd.first_child < 0) return node;
+            const int bx = pos.x >= nd.mid[0] ? 1 : 0, bz = pos.z >= nd.mid[2] ? 1 : 0, by = pos.y >= nd.mid[1] ? 1 : 0;
+            const int k = bx | (bz << 1) | (by << 2);
+            const int bit[3] = {bx, by, bz};
+            double lo[3], hi[3];
+            for (int ax = 0; ax < 3; ax++) {
+                if (k == 7) { lo[ax] = nd.mid[ax]; hi[ax] = nd.bmax[ax]; }
+                else if (bit[ax]) { lo[ax] = nd.u.in.lo2[ax]; hi[ax] = nd.u.in.hi2[ax]; }
+                else { lo[ax] = nd.bmin[ax]; hi[ax] = nd.mid[ax]; }
+            }
+            if (!box_contains(lo, hi, pos)) return -1;   // no child contains pos: box of -inf, nothing is collected
+            node = nd.first_child + k;
+        }
+    }
     while (S.pnodes[node].first_child >= 0) {
         const PNode& nd = S.pnodes[node];
         const int k = (pos.x >= nd.mid[0] ? 1 : 0) | (pos.z >= nd.mid[2] ? 2 : 0) | (pos.y >= nd.mid[1] ? 4 : 0);
@@ -1008,8 +1030,8 @@ GI_HD V3 gather_in_leaf(const Scene& S, int32_t node, V3 pos, V3 dir, float* hea
     // laid out (gi_layout.h): its result is the list of photon ranges [nb_off, nb_off + nb_cnt)
     const PNode& lf = S.pnodes[node];
     const PRange* ranges = S.pranges + lf.nb_off;
-    const int n_ranges = lf.nb_cnt;
-    const int ncand = lf.nb_photons;
+    const int n_ranges = lf.u.lf.nb_cnt;
+    const int ncand = lf.u.lf.nb_photons;
     if (n_cand_out) *n_cand_out = ncand;
     if (c) c->pcand += (unsigned long long)ncand;
     if (ncand == 0) return res;

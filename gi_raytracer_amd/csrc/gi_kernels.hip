@@ -484,7 +484,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
             continue;
         }
         const PNode& lf = S.pnodes[leaf0];
-        const int ncand = lf.nb_photons;
+        const int ncand = lf.u.lf.nb_photons;
         if (ncand == 0) continue;
         const PRange* ranges = S.pranges + lf.nb_off;
         GatherAcc a;
@@ -746,6 +746,7 @@ struct gi_ctx {
     DevBuf<double> d_tex_lut;
     DevBuf<int32_t> d_wleaf_id;
     bool wide_enabled = true;         // gi_set_wide_nodes
+    bool pn_planes_ok = false;        // the uploaded photon octree qualifies for the one-record-per-level descent
     DevBuf<int32_t> d_refs;
     DevBuf<LeafTri> d_leaf_tris;
     DevBuf<TriGeom> d_tris;
@@ -931,6 +932,8 @@ int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
     HIP_TRY(c, c->d_ph_dircol.upload(H.dircol));
     S.pnodes = c->d_pnodes.p; S.pranges = c->d_pranges.p; S.ph_pos = c->d_ph_pos.p; S.ph_dircol = c->d_ph_dircol.p;
     S.n_pnode = H.n_node; S.n_photon = H.n_photon;
+    c->pn_planes_ok = H.planes_ok;
+    S.pn_planes = (c->wide_enabled && c->pn_planes_ok) ? 1 : 0;
     return GI_OK;
 }
 
@@ -1218,7 +1221,8 @@ int gi_set_wide_nodes(gi_ctx* c, int enable)
     if (!c) return GI_E_INVALID;
     c->wide_enabled = enable != 0;
     c->S.wnodes = (c->wide_enabled && c->S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
-    return c->S.wnodes ? 1 : 0;
+    c->S.pn_planes = (c->wide_enabled && c->pn_planes_ok) ? 1 : 0;   // the photon octree's counterpart (gather_find_leaf)
+    return (c->S.wnodes ? 1 : 0) | (c->S.pn_planes ? 2 : 0);
 }
 
 int gi_set_render_mode(gi_ctx* c, int mode)

@@ -44,6 +44,7 @@ struct HostPhotons {
     std::vector<PRange> ranges;
     std::vector<double> pos, dircol;
     int32_t n_node = 0, n_photon = 0;
+    bool planes_ok = true;            // inner records' planes reproduce every child box (gather_find_leaf's one-record-per-level walk)
 };
 
 // Faure permutations and per-base digit-group tables of Halton_sampler (include/halton_sampler.h:573-603,890-1414).
@@ -371,7 +372,7 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
 // gather depends only on the leaf that contains the query point, so it is computed once per leaf here instead of per query.
 inline bool layout_photons(const gi_photon_map_desc* d, HostPhotons& H, std::string& err)
 {
-    H.nodes.clear(); H.ranges.clear(); H.pos.clear(); H.dircol.clear(); H.n_node = 0; H.n_photon = 0;
+    H.nodes.clear(); H.ranges.clear(); H.pos.clear(); H.dircol.clear(); H.n_node = 0; H.n_photon = 0; H.planes_ok = true;
     if (d->n_node <= 0 || d->n_photon <= 0) return true;
     if (!d->photons || !d->node_bbox || !d->node_child || !d->node_off) { err = "photons: null tables"; return false; }
     const int N = d->n_node;
@@ -436,6 +437,24 @@ inline bool layout_photons(const gi_photon_map_desc* d, HostPhotons& H, std::str
         if (!leaf) {
             const int c7 = d->node_child[(size_t)n * 8 + 7];
             for (int k = 0; k < 3; k++) t.mid[k] = d->node_bbox[(size_t)c7 * 6 + k];
+            // the planes the 8 children's boxes are made of (include/photonMap.cpp:139-149); H.planes_ok stays true only while every
+            // child's stored box equals, bit for bit, the box gather_find_leaf derives from them
+            for (int ax = 0; ax < 3; ax++) {
+                const int bitpos = ax == 0 ? 0 : (ax == 1 ? 2 : 1);   // x = bit 0, z = bit 1, y = bit 2
+                const int hs = 1 << bitpos;                           // a child on the high side of this axis only
+                const int ch = d->node_child[(size_t)n * 8 + hs];
+                t.u.in.lo2[ax] = d->node_bbox[(size_t)ch * 6 + ax]; t.u.in.hi2[ax] = d->node_bbox[(size_t)ch * 6 + 3 + ax];
+            }
+            for (int c = 0; c < 8; c++) {
+                const int ch = d->node_child[(size_t)n * 8 + c];
+                for (int ax = 0; ax < 3; ax++) {
+                    const int bitpos = ax == 0 ? 0 : (ax == 1 ? 2 : 1);
+                    const double clo = d->node_bbox[(size_t)ch * 6 + ax], chi = d->node_bbox[(size_t)ch * 6 + 3 + ax];
+                    const double wlo = c == 7 ? t.mid[ax] : (((c >> bitpos) & 1) ? t.u.in.lo2[ax] : t.bmin[ax]);
+                    const double whi = c == 7 ? t.bmax[ax] : (((c >> bitpos) & 1) ? t.u.in.hi2[ax] : t.mid[ax]);
+                    if (clo != wlo || chi != whi) H.planes_ok = false;
+                }
+            }
             continue;
         }
         double qlo[3], qhi[3];
@@ -462,8 +481,8 @@ inline bool layout_photons(const gi_photon_map_desc* d, HostPhotons& H, std::str
                 m = skip[m];
             }
         }
-        t.nb_cnt = (int32_t)H.ranges.size() - t.nb_off;
-        t.nb_photons = total;
+        t.u.lf.nb_cnt = (int32_t)H.ranges.size() - t.nb_off;
+        t.u.lf.nb_photons = total;
     }
     if (H.ranges.empty()) { PRange z; z.first = 0; z.count = 0; H.ranges.push_back(z); }
     H.n_node = N; H.n_photon = nref;

@@ -121,8 +121,10 @@ int gi_set_render_mode(gi_ctx*, int mode);
 /* Octree walk: 1 (default) = wide records, the boxes of a node's children tested together from the five planes per axis that
  * Octree::Node::partition builds them from (include/octree.cpp:318-328); 0 = one box test per node record.  Same box
  * arithmetic (include/bbox.h:47-73), same visiting order, same results; a tree whose children are not those exact octants
- * always takes the per-node walk.  Exists so that the two can be compared.  Returns 1 when the wide walk is in use after the
- * call (a scene is uploaded and its tree qualifies), 0 when not, negative on error.                                          */
+ * always takes the per-node walk.  The photon octree has the same option (PhotonMap::Node::partition builds its children from
+ * the same planes, include/photonMap.cpp:139-149): the descent of getBounds reads one record per level instead of two.
+ * Exists so that the two can be compared.  Returns a bit set, negative on error: 1 = the wide walk is in use after the call
+ * (a scene is uploaded and its tree qualifies), 2 = the uploaded photon octree is walked one record per level.               */
 int gi_set_wide_nodes(gi_ctx*, int enable);
 /* Upper bound on paths in flight in the wavefront pipeline (224 B each).  Default: as many as 80 % of the free HBM holds,
  * up to the whole frame (1080p x 256 spp = 531 M paths = 119 GB).                                                           */

@@ -110,7 +110,9 @@ class EmulRayTracer(gi.RayTracer):
 
     def set_wide_nodes(self, on):
         """Returns whether the wide-record walk is in use afterwards (False: the tree is not made of exact octants)."""
-        return bool(self.E.emul_set_wide(self.h, 1 if on else 0))
+        rc = self.E.emul_set_wide(self.h, 1 if on else 0)
+        self.photon_planes = bool(rc & 2)
+        return bool(rc & 1)
 
     def trace(self, rays):
         rays = gi._f64(rays).reshape(-1, 6); n = len(rays)

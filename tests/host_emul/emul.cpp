@@ -32,6 +32,7 @@ struct Emul {
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];
         S.pnodes = hp.nodes.data(); S.pranges = hp.ranges.data(); S.ph_pos = hp.pos.data(); S.ph_dircol = hp.dircol.data();
         S.n_pnode = hp.n_node; S.n_photon = hp.n_photon;
+        S.pn_planes = (wide && hp.planes_ok) ? 1 : 0;
         S.hdims = hdims.data(); S.htable = htable.data();
     }
 };
@@ -40,7 +41,7 @@ extern "C" {
 
 Emul* emul_create() { Emul* e = new Emul(); build_halton_tables(e->hdims, e->htable); e->bind(); return e; }
 void emul_destroy(Emul* e) { delete e; }
-int emul_set_wide(Emul* e, int on) { e->wide = on != 0; e->bind(); return e->S.wnodes != nullptr; }
+int emul_set_wide(Emul* e, int on) { e->wide = on != 0; e->bind(); return (e->S.wnodes != nullptr ? 1 : 0) | (e->S.pn_planes ? 2 : 0); }
 const char* emul_error(Emul* e) { return e->err.c_str(); }
 int emul_upload_scene(Emul* e, const gi_scene_desc* d)
 {

@@ -195,3 +195,28 @@ def check_wide_walk(rt, scene, set_wide):
     assert np.array_equal(hit_w, hit_n) and np.array_equal(ent_w[hit_w > 0], ent_n[hit_n > 0])
     assert np.array_equal(res_w[hit_w > 0].view(np.uint64), res_n[hit_n > 0].view(np.uint64))
     assert np.array_equal(vis_w, vis_n)
+
+
+def check_photon_descent(rt, scene, photons=20000):
+    """PhotonMap::getBounds walked one record per level (children's boxes from the parent's planes) and two records per level give
+    identical gathers: inside, outside and on the faces of the map."""
+    rt.tracePhotons(photons)
+    t = scene.tables()
+    bb = t["node_bbox"][0]
+    rs = np.random.RandomState(1)
+    pos = bb[:3] + (bb[3:] - bb[:3]) * (rs.rand(20000, 3) * 1.1 - 0.05)
+    ph = scene.photon_tables()
+    nb = ph["node_bbox"]
+    for j in range(2000):                       # queries exactly on planes of photon-map nodes
+        b = nb[rs.randint(len(nb))]
+        pos[j, rs.randint(3)] = b[rs.randint(6)]
+    q = np.concatenate([pos, rs.randn(len(pos), 3)], 1)
+    rt.set_wide_nodes(True)
+    assert rt.photon_planes, "the photon octree was not accepted for the one-record descent"
+    a, na = rt.samplePhotons(q)
+    rt.set_wide_nodes(False)
+    assert not rt.photon_planes
+    b, nbc = rt.samplePhotons(q)
+    rt.set_wide_nodes(True)
+    assert (na > 0).mean() > 0.1 and (na == 0).any()
+    assert np.array_equal(na, nbc) and np.array_equal(a.view(np.uint64), b.view(np.uint64))

@@ -45,6 +45,11 @@ def test_wide_walk_equals_per_node_walk(setup):
     pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
 
 
+def test_photon_octree_descent_variants_agree():
+    scene = pc.load_scene("caustics")
+    pc.check_photon_descent(el.EmulRayTracer().setScene(scene), scene)
+
+
 def test_gather_matches_reference_table(setup):
     name, scene, rt, fx = setup
     if "photons" not in fx:

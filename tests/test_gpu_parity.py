@@ -117,6 +117,11 @@ def test_wide_and_per_node_frames_are_identical():
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
+def test_photon_octree_descent_variants_agree():
+    scene = pc.load_scene("caustics")
+    pc.check_photon_descent(gi.RayTracer(0).setScene(scene), scene)
+
+
 def test_gather_matches_reference_table(setup):
     name, scene, rt, fx = setup
     if "photons" not in fx:
