@@ -16,8 +16,9 @@ _dp, _ip, _up = gi._dp, gi._ip, gi._up
 def lib():
     global _LIB
     if _LIB is None:
-        subprocess.run(["make", "-C", _DIR], check=True, stdout=subprocess.DEVNULL)
-        L = C.CDLL(os.path.join(_DIR, "libgi_emul.so"))
+        asan = os.environ.get("GI_EMUL_ASAN") == "1"   # sanitizer build: LD_PRELOAD=$(gcc -print-file-name=libasan.so) GI_EMUL_ASAN=1 pytest ...
+        subprocess.run(["make", "-C", _DIR] + (["asan"] if asan else []), check=True, stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(_DIR, "libgi_emul_asan.so" if asan else "libgi_emul.so"))
         vp = C.c_void_p
         L.emul_create.restype = vp
         L.emul_destroy.argtypes = [vp]
