@@ -560,12 +560,14 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
 // such bounces, so the finisher runs in stages: stage k gives each wave `lanes` paths (lanes 0..lanes-1, the rest idle),
 // advances them at most `max_bounces` vertices, and hands the survivors to stage k+1, which spreads them thinner.  The
 // survivor count stays on the device (n_in_dev): no host round trip between stages.
+#define GI_FINISH_BLOCK 512   // 8 waves: with 64 KB of heaps and 64 KB of octree records one block fills a CU, at the 2 waves per SIMD the registers allow
 template <int FEAT, int WIDE>
-__global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+__global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                         const uint32_t* q_in, const unsigned int* n_in_dev, uint32_t n_in_host, int lanes, int max_bounces,
                                                         uint32_t* q_out, unsigned int* n_out, double* lbuf)
 {
-    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
+    __shared__ float heap[GI_GATHER_K * GI_FINISH_BLOCK];
+    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // a lone path's bounce is a chain of dependent node reads: LDS, not L2
     const uint32_t n_in = n_in_dev ? *n_in_dev : n_in_host;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -574,13 +576,11 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_finish(Scene S, uint64_t seed, 
     for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
         const uint32_t slot = q_in[i];
         PathRec p = pool[slot];
-        typename std::conditional<WIDE != 0, GlobalWide, GlobalNodes>::type N;
-        if constexpr (WIDE != 0) N.g = S.wnodes; else N.g = S.tnodes;
         bool alive = true;
         for (int b = 0;;) {
             if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; break; }
             const int fl = stage_shade_nodes<FEAT>(S, N, p, seed, nullptr);
-            if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_BLOCK, nullptr);
+            if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_FINISH_BLOCK, nullptr);
             if (!(fl & ST_CONTINUE)) { alive = false; break; }
             if (++b >= max_bounces) break;
         }
@@ -1095,7 +1095,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
     if (!g_trace) {
         g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<7, 1>, lds_nodes, GI_TRACE_BLOCK);
-        g_shade = grid_for(c, (const void*)k_st_shade<7, 1>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<7, 1>);
+        g_shade = grid_for(c, (const void*)k_st_shade<7, 1>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<7, 1>, lds_nodes, GI_FINISH_BLOCK);
     }
     hipStream_t st = c->stream;
     const bool wide = c->S.wnodes != nullptr;
@@ -1147,7 +1147,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
                     const int lanes = c->finish_plan[k].first, vertices = k + 1 == n_stage ? GI_MAX_DEPTH + 1 : c->finish_plan[k].second;
                     const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
                     stage_begin(c, STG_FINISH);
-                    hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1> : k_st_finish<7, 0>) : wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(g_finish), dim3(GI_BLOCK), 0, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
+                    hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1> : k_st_finish<7, 0>) : wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(g_finish), dim3(GI_FINISH_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
                                        fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, c->d_lbuf.p);
                     stage_end(c);
                     launches++;
