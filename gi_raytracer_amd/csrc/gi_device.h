@@ -1135,17 +1135,23 @@ GI_HD V3 shading_normal(const Scene& S, const HitRec& h)  // include/entities.h:
 // compacted queue of PathRec indices (gi_kernels.hip).
 struct alignas(16) PathRec {    // 224 B, one per path in flight (HBM-resident in the wavefront pipeline)
     double o[3], d[3];          // current ray (d normalised)
-    double T[3], contrib[3];    // throughput prod f_j ; the reference's `contrib` (roulette weight)
-    double L[3];                // radiance accumulated so far
-    double hpos[3], hu, hv;     // hit of the current segment
-    double gdir[3], gcoef[3];   // pending photon gather: direction (= refDir) and factor T*color
     uint32_t stream;            // Halton sample index = RNG stream
     int32_t depth;              // -1: slot unused
     int32_t htri;
-    uint32_t pad;
+    uint32_t pad;               // -- the first 64 B are all a new path needs and all the trace stage reads
+    double T[3], contrib[3];    // throughput prod f_j ; the reference's `contrib` (roulette weight).  At depth 0 they are 1 and L is 0 by
+    double L[3];                // definition: the stages do not read them there, so a new path does not have to write them (path_begin_lean)
+    double hpos[3], hu, hv;     // hit of the current segment
+    double gdir[3], gcoef[3];   // pending photon gather: direction (= refDir) and factor T*color
 };
 enum { ST_CONTINUE = 1, ST_GATHER = 2 };
 
+GI_HD void path_begin_lean(PathRec& p, const Ray& ray, uint32_t sample)   // one 64-byte store: what a depth-0 path consists of
+{
+    p.o[0] = ray.o.x; p.o[1] = ray.o.y; p.o[2] = ray.o.z;
+    p.d[0] = ray.d.x; p.d[1] = ray.d.y; p.d[2] = ray.d.z;
+    p.stream = sample; p.depth = 0; p.htri = -1; p.pad = 0;
+}
 GI_HD void path_begin(PathRec& p, const Ray& ray, uint32_t sample)
 {
     p.o[0] = ray.o.x; p.o[1] = ray.o.y; p.o[2] = ray.o.z;
@@ -1162,7 +1168,8 @@ GI_HD bool stage_trace_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_
     Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
     HitRec h;
     if (!trace_nodes<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, h, c)) {
-        V3 L = ld3(p.L) + ld3(p.T) * ld3(S.ambient);
+        const bool first = p.depth == 0;   // L = 0, T = 1 (PathRec)
+        V3 L = (first ? v3(0, 0, 0) : ld3(p.L)) + (first ? v3(1, 1, 1) : ld3(p.T)) * ld3(S.ambient);
         p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
         return false;
     }
@@ -1205,7 +1212,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         emissive = tex_get(S, m.etex, emissive, tu, tv);
         tex_a = tex_alpha(S, m.dtex, tu, tv);
     }
-    V3 refDir, f = v3(1, 1, 1), i = v3(0, 0, 0), contrib = ld3(p.contrib);
+    V3 refDir, f = v3(1, 1, 1), i = v3(0, 0, 0), contrib = depth == 0 ? v3(1, 1, 1) : ld3(p.contrib);
     double roughness, offset = GI_SHADOW_BIAS;
     secondary_ray(ray, m, color, tex_a, norm, sx, sy, refDir, f, roughness, contrib, offset, rng);
     if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:209-228: the segment may end in the medium instead
@@ -1244,7 +1251,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         }
     }
     p.contrib[0] = contrib.x; p.contrib[1] = contrib.y; p.contrib[2] = contrib.z;
-    V3 T = ld3(p.T), L = ld3(p.L);
+    V3 T = depth == 0 ? v3(1, 1, 1) : ld3(p.T), L = depth == 0 ? v3(0, 0, 0) : ld3(p.L);
     double q = comp_max(contrib);
     if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
         f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));

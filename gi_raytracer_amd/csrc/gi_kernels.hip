@@ -346,7 +346,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec
         slot_sample[slot] = id;
         uint32_t idx;
         Ray ray = primary_ray(S, F, s_begin + (int)srel, x, global_row(F, ly), idx);
-        path_begin(pool[slot], ray, idx);
+        path_begin_lean(pool[slot], ray, idx);
         q_new[i] = slot;
     }
 }
