@@ -87,7 +87,8 @@ struct LeafTri {            // 80 B: the test record again, stored once per leaf
     int32_t tri;            // triangle index (shading record, RNG key)
     uint32_t matflags;      // material << 3 | flags
 };
-struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; double t0[2], t1[2], t2[2]; };  // 144 B, read once per shaded hit (t*: vertex texCoords)
+struct TriShade { double n0[3], n1[3], n2[3], fnorm[3]; };  // 96 B, read once per shaded hit
+struct TriUV { double t0[2], t1[2], t2[2]; };                // 48 B: vertex texCoords, read only by textured scenes (GI_FEAT_TEX)
 struct Mat { double roughness, opacity, ior, diffuse[3], emissive[3]; int32_t dtex, etex; };   // dtex / etex: texture record or -1 = the constant colour
 struct TexD {               // include/material.h:10-81
     int32_t kind;           // 0 texture(col), 1 checkerboard, 2 imageTexture
@@ -119,6 +120,7 @@ struct Scene {
     const LeafTri* leaf_tris; // [n_refs], parallel to leaf_refs
     const TriGeom* tris;
     const TriShade* shade;
+    const TriUV* tri_uv;      // [n_tri], only when n_tex > 0
     const Mat* mats;
     const LightD* lights;
     const PNode* pnodes;
@@ -487,7 +489,7 @@ GI_HD void ent_uv(const Scene& S, const Tri& g, uint32_t flags, int32_t ti, doub
         tv = .5 + asin(d.y) / GI_PI;
         tu = .5 + atan2(d.z, d.x) / (2 * GI_PI);
     } else if (flags & 1u) {
-        const TriShade& sh = S.shade[ti];
+        const TriUV& sh = S.tri_uv[ti];
         const double w = (1 - u - v);
         tu = w * sh.t0[0] + u * sh.t1[0] + v * sh.t2[0];
         tv = w * sh.t0[1] + u * sh.t1[1] + v * sh.t2[1];

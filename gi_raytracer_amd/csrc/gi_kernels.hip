@@ -742,6 +742,7 @@ struct gi_ctx {
     DevBuf<TNode> d_tnodes;
     DevBuf<WNode> d_wnodes;
     DevBuf<TexD> d_texs;
+    DevBuf<TriUV> d_tri_uv;
     DevBuf<unsigned char> d_tex_pixels;
     DevBuf<double> d_tex_lut;
     DevBuf<int32_t> d_wleaf_id;
@@ -885,6 +886,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_wnodes.upload(H.wnodes));
     HIP_TRY(c, c->d_wleaf_id.upload(H.wleaf_id));
     HIP_TRY(c, c->d_texs.upload(H.texs));
+    HIP_TRY(c, c->d_tri_uv.upload(H.tri_uv));
     HIP_TRY(c, c->d_tex_pixels.upload(H.tex_pixels));
     HIP_TRY(c, c->d_tex_lut.upload(H.tex_lut));
     HIP_TRY(c, c->d_refs.upload(H.refs));
@@ -902,7 +904,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     S.n_wnode = (int32_t)H.wnodes.size();
     S.wnodes = (c->wide_enabled && S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
     S.wleaf_id = c->d_wleaf_id.p;
-    S.texs = c->d_texs.p; S.tex_pixels = c->d_tex_pixels.p; S.tex_lut = c->d_tex_lut.p; S.n_tex = H.n_tex();
+    S.tri_uv = c->d_tri_uv.p; S.texs = c->d_texs.p; S.tex_pixels = c->d_tex_pixels.p; S.tex_lut = c->d_tex_lut.p; S.n_tex = H.n_tex();
     S.has_spheres = 0;
     S.fogs = c->d_fogs.p; S.fog_grid = c->d_fog_grid.p; S.n_fog = H.n_fog();
     for (const TriGeom& g : H.tris) if (g.flags & 4u) S.has_spheres = 1;

@@ -27,6 +27,7 @@ struct HostScene {
     std::vector<LeafTri> leaf_tris;
     std::vector<TriGeom> tris;
     std::vector<TriShade> shade;
+    std::vector<TriUV> tri_uv;
     std::vector<Mat> mats;
     std::vector<LightD> lights;
     std::vector<FogD> fogs;
@@ -272,6 +273,7 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
     H.refs.assign(d->node_ent_idx, d->node_ent_idx + d->node_ent_off[d->n_node]);
     H.tris.resize((size_t)d->n_tri);
     H.shade.resize((size_t)d->n_tri);
+    H.tri_uv.resize((size_t)d->n_tri);
     for (int i = 0; i < d->n_tri; i++) {
         const double* P = d->tri_pos + (size_t)i * 9;
         const double* N = d->tri_nrm + (size_t)i * 9;
@@ -295,7 +297,8 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         V3 fn = sphere ? v3(0, 0, 0) : normalize(cross((p1 - p0), (p2 - p0)));                   // include/entities.h:339
         s.fnorm[0] = fn.x; s.fnorm[1] = fn.y; s.fnorm[2] = fn.z;
         if (sphere) { s.n0[0] = P[0]; s.n0[1] = P[1]; s.n0[2] = P[2]; }                         // centre, for the shading normal
-        for (int k = 0; k < 2; k++) { s.t0[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + k] : 0; s.t1[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + 2 + k] : 0; s.t2[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + 4 + k] : 0; }
+        TriUV& tu = H.tri_uv[i];
+        for (int k = 0; k < 2; k++) { tu.t0[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + k] : 0; tu.t1[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + 2 + k] : 0; tu.t2[k] = d->tri_uv ? d->tri_uv[(size_t)i * 6 + 4 + k] : 0; }
     }
     H.leaf_tris.resize(H.refs.size());
     for (size_t r = 0; r < H.refs.size(); r++) {

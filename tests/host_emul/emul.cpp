@@ -27,7 +27,7 @@ struct Emul {
         S.n_wnode = (int32_t)hs.wnodes.size();
         S.wnodes = (wide && S.n_wnode > 0) ? hs.wnodes.data() : nullptr;
         S.wleaf_id = hs.wleaf_id.data();
-        S.texs = hs.texs.data(); S.tex_pixels = hs.tex_pixels.data(); S.tex_lut = hs.tex_lut.data(); S.n_tex = hs.n_tex();
+        S.tri_uv = hs.tri_uv.data(); S.texs = hs.texs.data(); S.tex_pixels = hs.tex_pixels.data(); S.tex_lut = hs.tex_lut.data(); S.n_tex = hs.n_tex();
         S.fogs = hs.fogs.data(); S.fog_grid = hs.fog_grid.data(); S.n_fog = hs.n_fog();
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];
         S.pnodes = hp.nodes.data(); S.pranges = hp.ranges.data(); S.ph_pos = hp.pos.data(); S.ph_dircol = hp.dircol.data();
