@@ -92,17 +92,27 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the render hot path has no CPU fallback")
+    # rehearsal of the N > 1 path on a one-GPU box: GI_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo (RCCL cannot
+    # run two ranks on one device); numbers from such a run mean nothing, it only exercises the code path
+    rehearsal = os.environ.get("GI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- setup (untimed): scene tables, octree, photon emission on the device, photon octree
     scene = pc.load_scene(args.scene)
     rt = gi.RayTracer(local_rank).setScene(scene)
+    if rehearsal and world > 1:
+        rt.set_pool_slots(args.width * args.height * args.spp // world // 2 + 1)   # several ranks share one device's memory
     rt.set_stream(torch.cuda.current_stream().cuda_stream)
     rt.set_render_mode(args.mode)
     if args.pool > 0:

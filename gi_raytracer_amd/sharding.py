@@ -41,7 +41,15 @@ class FrameGather:
         if self.world == 1:
             self.frame[:] = self.local[: self.h]
             return self.frame
-        self.dist.gather(self.local, self.parts, dst=0)
+        if self.dist.get_backend() == "gloo" and self.local.is_cuda:   # rehearsal on one device: gloo gathers host tensors
+            host = self.local.cpu()
+            parts = [self.torch.zeros_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(host, parts, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.parts[r].copy_(parts[r])
+        else:
+            self.dist.gather(self.local, self.parts, dst=0)
         if self.rank == 0:
             for r in range(self.world):
                 self.frame[self.index[r]] = self.parts[r][: len(self.rows[r])]
