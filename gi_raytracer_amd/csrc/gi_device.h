@@ -109,7 +109,7 @@ struct alignas(128) PNode { // 128 B: photon octree node; the 8 children of a no
     } u;                                                      // include/photonMap.cpp:139-149), child 7 [mid, max], low-side children [min, mid]
 };
 struct PRange { int32_t first, count; };   // photons are stored leaf by leaf in the reference's DFS order
-struct HaltonDim { uint32_t P, n, off; float scale; };
+struct HaltonDim { uint32_t P, n, off; float scale; uint32_t mlo, mhi, pad[2]; };   // (mhi:mlo) = floor((2^64 - 1) / P) + 1: x / P = hi64(x * m) for every 32-bit x
 struct FogD { double pos[3], size[3], col[3], d, sc, bmin[3], bmax[3]; int32_t grid_off, grid_n; };   // HeightFog, include/atmosphere.h:30-83
 
 struct Scene {
@@ -141,6 +141,7 @@ struct Scene {
     int32_t has_spheres;      // 0: triangles only
     int32_t n_fog;
     double ambient[3];
+    double root_bmin[3], root_bmax[3];   // box of octree node 0 (kernel argument: no memory round trip before a walk starts)
 };
 
 struct Counters { unsigned long long v_trace, v_shadow, tri, shaded, pcand, traces, shadows, gathers; };
@@ -234,13 +235,23 @@ GI_HD float halton_sample(const Scene& S, uint32_t dim, uint32_t index)
         return r.f - 1.f;
     }
     const HaltonDim D = S.hdims[dim];
-    uint32_t sum = 0;
-    for (uint32_t k = 0; k < D.n; k++) {
-        uint32_t q = index / D.P;
-        uint32_t d = index - q * D.P;
-        sum = sum * D.P + (uint32_t)S.htable[D.off + d];
-        index = q;
+    // digit groups first (division by the table size as a multiplication: exact for every 32-bit index and P <= 1619), then all table
+    // reads at once -- they do not depend on each other, and up to 7 dependent L2 round trips per sample were what this cost
+    uint32_t dg[7], idx = index;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        unsigned long long t = ((unsigned long long)idx * D.mlo) >> 32;
+        t += (unsigned long long)idx * D.mhi;
+        const uint32_t q = (uint32_t)(t >> 32);
+        dg[k] = idx - q * D.P;
+        idx = q;
     }
+    uint32_t tv[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) tv[k] = (uint32_t)k < D.n ? (uint32_t)S.htable[D.off + dg[k]] : 0u;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) if ((uint32_t)k < D.n) sum = sum * D.P + tv[k];
     return (float)sum * D.scale;
 }
 struct HaltonEnumD { uint32_t p2, p3, m_x, m_y, inc; float scale_x, scale_y; };
@@ -450,7 +461,7 @@ GI_HD bool tri_hit(const Tri& g, const Ray& ray, double& u, double& v, double& t
     return true;
 }
 
-struct HitRec { V3 pos; double u, v; int32_t tri; double tu, tv; };   // u, v barycentric; tu, tv = the reference's `uv` (GI_FEAT_TEX only)
+struct HitRec { V3 pos; double u, v; int32_t tri; uint32_t mf; double tu, tv; };   // mf = LeafTri::matflags of the hit (material << 3 | flags)   // u, v barycentric; tu, tv = the reference's `uv` (GI_FEAT_TEX only)
 
 // ------------------------------------------------------------------------------------------------ textures (include/material.h:10-81)
 GI_HD const unsigned char* tex_pixel(const Scene& S, const TexD& x, double tu, double tv)   // image.pixelColor(...), include/material.h:65
@@ -641,8 +652,7 @@ template <class WN>
 GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0)
 {
     k.node = 0; k.m = 0; k.lo = 0; k.hi = 0;
-    const TNode& root = S.tnodes[0];
-    if (!box_hit(root.bmin, root.bmax, ray, tmin0, tmax0)) return false;
+    if (!box_hit(S.root_bmin, S.root_bmax, ray, tmin0, tmax0)) return false;
     k.m = W.with(0, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
     return true;
 }
@@ -673,7 +683,7 @@ GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rn
             }
             double d2 = len2(hp - ray.o);
             if (!intersected || d2 < best_d2) {
-                best.pos = hp; best.u = u; best.v = v; best.tri = ti;
+                best.pos = hp; best.u = u; best.v = v; best.tri = ti; best.mf = g.matflags;
                 if (FEAT & GI_FEAT_TEX) { best.tu = cu; best.tv = cv; }
                 best_d2 = d2;
                 intersected = true;
@@ -780,7 +790,7 @@ GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng
             }
             double d2 = len2(hp - ray.o);
             if (!intersected || d2 < best_d2) {
-                best.pos = hp; best.u = u; best.v = v; best.tri = ti;
+                best.pos = hp; best.u = u; best.v = v; best.tri = ti; best.mf = g.matflags;
                 if (FEAT & GI_FEAT_TEX) { best.tu = cu; best.tv = cv; }
                 best_d2 = d2;
                 intersected = true;
@@ -1125,8 +1135,8 @@ GI_HD void secondary_ray(const Ray& ray, const Mat& m, V3 color, double tex_a, V
 GI_HD V3 shading_normal(const Scene& S, const HitRec& h)  // include/entities.h:478-485
 {
     const TriShade& sh = S.shade[h.tri];
-    if (S.tris[h.tri].flags & 4u) return normalize(h.pos - ld3(sh.n0));   // sphere: normalize(intersect - pos), include/entities.h:84
-    if (S.tris[h.tri].flags & 1u) return (1 - h.u - h.v) * ld3(sh.n0) + h.u * ld3(sh.n1) + h.v * ld3(sh.n2);
+    if (h.mf & 4u) return normalize(h.pos - ld3(sh.n0));   // sphere: normalize(intersect - pos), include/entities.h:84
+    if (h.mf & 1u) return (1 - h.u - h.v) * ld3(sh.n0) + h.u * ld3(sh.n1) + h.v * ld3(sh.n2);
     return ld3(sh.fnorm);
 }
 
@@ -1140,7 +1150,8 @@ struct alignas(16) PathRec {    // 224 B, one per path in flight (HBM-resident i
     uint32_t stream;            // Halton sample index = RNG stream
     int32_t depth;              // -1: slot unused
     int32_t htri;
-    uint32_t pad;               // -- the first 64 B are all a new path needs and all the trace stage reads
+    uint32_t pad;               // matflags of the hit (material << 3 | flags): the shade stage needs no entity record for them
+                                // -- the first 64 B are all a new path needs and all the trace stage reads
     double T[3], contrib[3];    // throughput prod f_j ; the reference's `contrib` (roulette weight).  At depth 0 they are 1 and L is 0 by
     double L[3];                // definition: the stages do not read them there, so a new path does not have to write them (path_begin_lean)
     double hpos[3], hu, hv;     // hit of the current segment
@@ -1176,7 +1187,7 @@ GI_HD bool stage_trace_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_
         return false;
     }
     p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
-    p.hu = h.u; p.hv = h.v; p.htri = h.tri;
+    p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.pad = h.mf;
     if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
     return true;
 }
@@ -1201,10 +1212,10 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     if (c) c->shaded++;
     Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
     HitRec h;
-    h.pos = ld3(p.hpos); h.u = p.hu; h.v = p.hv; h.tri = p.htri;
+    h.pos = ld3(p.hpos); h.u = p.hu; h.v = p.hv; h.tri = p.htri; h.mf = p.pad;
     float sx = halton_sample(S, 2 + 2 * depth, p.stream);
     float sy = halton_sample(S, 3 + 2 * depth, p.stream);
-    const Mat& m = S.mats[S.tris[h.tri].mat];
+    const Mat& m = S.mats[h.mf >> 3];
     V3 norm = shading_normal(S, h);
     V3 color = ld3(m.diffuse), emissive = ld3(m.emissive);
     double tex_a = 1;
@@ -1382,16 +1393,14 @@ GI_HD bool emit_photon(const Scene& S, int32_t i, int32_t li, int32_t count, int
         int depth = 0;
         bool term = false, isCaustic = false;
         if (!trace(S, r, rng, P_PH_TRACE0_ALPHA, h, nullptr)) { tries++; continue; }
-        int32_t current = h.tri;
         V3 hit = h.pos;
         while (depth < max_depth && !term) {
             rng.depth = (uint32_t)tries * 16u + (uint32_t)depth + 1u;
-            double roughness = S.mats[S.tris[current].mat].roughness;
+            double roughness = S.mats[h.mf >> 3].roughness;
             if (roughness < 0.1) {
                 if (!trace(S, r, rng, P_TRACE_ALPHA, h, nullptr)) { term = true; continue; }
-                current = h.tri;
                 hit = h.pos;
-                const Mat& m = S.mats[S.tris[current].mat];
+                const Mat& m = S.mats[h.mf >> 3];
                 V3 norm = shading_normal(S, h);
                 V3 refDir, f, contrib = v3(0, 0, 0);
                 double offset = GI_SHADOW_BIAS;

@@ -381,11 +381,10 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
 // coarse direction -- rays that are neighbours in this order walk the same nodes for about the same number of steps
 __device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& p)
 {
-    const TNode& root = S.tnodes[0];
     uint32_t m = 0;
     uint32_t q[3];
     for (int k = 0; k < 3; k++) {
-        double f = (p.o[k] - root.bmin[k]) / (root.bmax[k] - root.bmin[k]);
+        double f = (p.o[k] - S.root_bmin[k]) / (S.root_bmax[k] - S.root_bmin[k]);
         f = f < 0.0 ? 0.0 : (f > 0.999 ? 0.999 : f);
         q[k] = (uint32_t)(f * 64.0);
     }
@@ -901,6 +900,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.leaf_tris = c->d_leaf_tris.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
     S.mats = c->d_mats.p; S.lights = c->d_lights.p;
     S.n_node = H.n_node; S.n_tri = H.n_tri; S.n_light = H.n_light;
+    for (int k = 0; k < 3; k++) { S.root_bmin[k] = H.tnodes[0].bmin[k]; S.root_bmax[k] = H.tnodes[0].bmax[k]; }
     S.n_wnode = (int32_t)H.wnodes.size();
     S.wnodes = (c->wide_enabled && S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
     S.wleaf_id = c->d_wleaf_id.p;

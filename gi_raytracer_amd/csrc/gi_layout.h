@@ -84,6 +84,9 @@ inline void build_halton_tables(std::vector<HaltonDim>& dims, std::vector<uint16
         while (full * P < 4294967296ull) { full *= P; groups++; }               // groups with (b^g)^n < 2^32
         dims[d].P = P; dims[d].n = groups; dims[d].off = (uint32_t)table.size();
         dims[d].scale = float(0.9999998807907104 / (double)full);
+        // groups <= 7: the longest chain is base 23 (23^7 < 2^32 <= 23^8); halton_sample unrolls 7 (all 256 dims are checked bit for bit by the tests)
+        const unsigned long long magic = 0xffffffffffffffffull / P + 1ull;
+        dims[d].mlo = (uint32_t)magic; dims[d].mhi = (uint32_t)(magic >> 32); dims[d].pad[0] = dims[d].pad[1] = 0;
         for (unsigned i = 0; i < P; i++) {
             unsigned rest = i;
             uint16_t inv = 0;

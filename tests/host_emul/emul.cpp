@@ -24,6 +24,7 @@ struct Emul {
         S.tnodes = hs.tnodes.data(); S.leaf_refs = hs.refs.data(); S.leaf_tris = hs.leaf_tris.data(); S.tris = hs.tris.data(); S.shade = hs.shade.data();
         S.mats = hs.mats.data(); S.lights = hs.lights.data();
         S.n_node = hs.n_node; S.n_tri = hs.n_tri; S.n_light = hs.n_light; S.has_spheres = 1;
+        if (!hs.tnodes.empty()) for (int k = 0; k < 3; k++) { S.root_bmin[k] = hs.tnodes[0].bmin[k]; S.root_bmax[k] = hs.tnodes[0].bmax[k]; }
         S.n_wnode = (int32_t)hs.wnodes.size();
         S.wnodes = (wide && S.n_wnode > 0) ? hs.wnodes.data() : nullptr;
         S.wleaf_id = hs.wleaf_id.data();
