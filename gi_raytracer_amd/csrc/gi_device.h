@@ -37,6 +37,11 @@
 namespace gi {
 
 // ------------------------------------------------------------------------------------------------ constants (include/util.h:14-31)
+#if defined(__clang__)
+#define GI_UNROLL _Pragma("unroll")
+#else
+#define GI_UNROLL
+#endif
 #define GI_EPSILON 0.00001
 #define GI_SHADOW_BIAS 0.0001
 #define GI_MIN_DEPTH 2
@@ -238,7 +243,7 @@ GI_HD float halton_sample(const Scene& S, uint32_t dim, uint32_t index)
     // digit groups first (division by the table size as a multiplication: exact for every 32-bit index and P <= 1619), then all table
     // reads at once -- they do not depend on each other, and up to 7 dependent L2 round trips per sample were what this cost
     uint32_t dg[7], idx = index;
-#pragma unroll
+    GI_UNROLL
     for (int k = 0; k < 7; k++) {
         unsigned long long t = ((unsigned long long)idx * D.mlo) >> 32;
         t += (unsigned long long)idx * D.mhi;
@@ -247,10 +252,10 @@ GI_HD float halton_sample(const Scene& S, uint32_t dim, uint32_t index)
         idx = q;
     }
     uint32_t tv[7];
-#pragma unroll
+    GI_UNROLL
     for (int k = 0; k < 7; k++) tv[k] = (uint32_t)k < D.n ? (uint32_t)S.htable[D.off + dg[k]] : 0u;
     uint32_t sum = 0;
-#pragma unroll
+    GI_UNROLL
     for (int k = 0; k < 7; k++) if ((uint32_t)k < D.n) sum = sum * D.P + tv[k];
     return (float)sum * D.scale;
 }
