@@ -35,7 +35,7 @@ def floor(size, n):
     return pos, nrm, uv
 
 
-def build(n_lat=160, n_lon=320, textured=False):
+def build(n_lat=160, n_lon=320, textured=False, fog=False):
     s = gi.Scene()
     if textured:
         black = s.add_color_texture((0, 0, 0)); white = s.add_color_texture((1, 1, 1))
@@ -45,6 +45,8 @@ def build(n_lat=160, n_lon=320, textured=False):
         m_floor = s.add_material(1, 1, 1, (0.8, 0.8, 0.8)); m_glass = s.add_material(0, 0, 1.5, (1, 1, 1)); m_diff = s.add_material(1, 1, 1, (0.8, 0.3, 0.2))
     for (pos, nrm, uv), m in ((floor(8, 64), m_floor), (blob((-1.5, 1.6, 1.5), 1.4, n_lat, n_lon, 0.08, 1), m_glass), (blob((1.8, 1.3, -1.6), 1.2, n_lat, n_lon, 0.12, 2), m_diff)):
         s.add_triangles(pos, nrm, uv, np.full(len(pos), m, np.int32))
+    if fog:   # a HeightFog slab over the floor (include/atmosphere.h:30-83): position, size, colour, density, scatter, noise scale
+        s.add_height_fog((0, .6, 0), (10, 1.2, 10), (0.8, 0.85, 1.0), 2.0, .5, 4)
     s.add_light((2, 7, 3), (60, 60, 60), 0.1)
     s.set_ambient((0.03, 0.04, 0.06))
     return s.rebuild()
@@ -54,19 +56,21 @@ if __name__ == "__main__":
     import sys, time, torch
     sys.path.insert(0, "tests")
     import parity_checks as pc
-    t0 = time.time(); scene = build(); t = scene.tables()
+    fog = "--fog" in sys.argv
+    uhd = "--4k" in sys.argv
+    t0 = time.time(); scene = build(fog=fog); t = scene.tables()
     print("triangles", len(t["tri_pos"]), "nodes", len(t["node_bbox"]), "refs", len(t["node_ent_idx"]), "host build %.2f s" % (time.time() - t0), flush=True)
     rt = gi.RayTracer(0).setScene(scene)
     ph, _ = rt.tracePhotons(100000)
-    w, h, spp = 1920, 1080, 64
+    w, h, spp = (3840, 2160, 64) if uhd else (1920, 1080, 64)
     p = rt.params(w, h, min_samples=spp, max_samples=spp)
     buf = torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0")
     for _ in range(2):
         rt.run_device(p, buf.data_ptr()); torch.cuda.synchronize()
     ms = rt.last_render_ms()[0]
-    print("1080p x %d spp: %.1f ms = %.1f Msamples/s" % (spp, ms, w * h * spp / ms / 1e3), {k: round(v, 1) for k, v in rt.last_stage_ms().items()}, "wide", rt.set_wide_nodes(True), flush=True)
+    print(("4K" if uhd else "1080p") + (" + fog" if fog else "") + " x %d spp: %.1f ms = %.1f Msamples/s" % (spp, ms, w * h * spp / ms / 1e3), {k: round(v, 1) for k, v in rt.last_stage_ms().items()}, "wide", rt.set_wide_nodes(True), flush=True)
     o = pc.oracle_for(scene); o.set_photons(ph); o.build_photon_map()
-    rows = np.array([200, 540, 800], np.int32)
+    rows = np.array([200, 540, 800], np.int32) * (2 if uhd else 1)
     t0 = time.time(); lin, cnt = o.render_rows(w, h, rows, spp, rt.seed, 16); dt = time.time() - t0
     img = buf.cpu().numpy().astype(np.float64)
     d = np.abs(img[rows] - lin[rows]).max(axis=2)
