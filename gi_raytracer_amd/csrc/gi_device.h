@@ -615,6 +615,7 @@ GI_HD void wide_leaf_box(const WNode* w, int slot, double* lmin, double* lmax)  
 }
 struct GlobalWide {
     static constexpr bool kWide = true;
+    static constexpr bool kCoop = false;
     const WNode* g;
     template <class F> GI_HDM auto with(int32_t i, F&& f) const { return f(g + i); }
 };
@@ -745,6 +746,119 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
     return true;
 }
 
+#if defined(__HIPCC__)
+// ---- one ray per WAVE (the finisher's last stages: a handful of depth-65 paths, each a chain of dependent bounces).  All 64 lanes
+// carry the same ray and walk the nodes together; at a leaf every lane tests its own triangle.  The reference's sequential loop
+// (include/raytracer.h:447-468: take a hit when it is the first or strictly nearer than the best so far; remember if any taken hit
+// lay inside the leaf's box) is reproduced from an exclusive prefix minimum over the lanes: lane j "takes" its hit exactly when
+// d2_j < min(best before the leaf, d2_i of the accepted hits i < j).  The last taking lane holds the final best.
+template <int FEAT, class WN>
+__device__ __forceinline__ bool trace_wide_coop(const Scene& S, const WN& W, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best)
+{
+    if constexpr ((FEAT & GI_FEAT_TEX) != 0) return trace_wide<FEAT>(S, W, ray, rng, alpha_purpose, best);   // the carried uv is sequential: every lane walks alone
+    else {
+    const int lane = (int)(threadIdx.x & 63u);
+    const WRay wr = wray_make(ray);
+    bool intersected = false;
+    double best_d2 = 0;
+    WWalk k;
+    if (!wwalk_begin(S, W, k, ray, wr, 0.0, INFINITY)) return false;
+    for (;;) {
+        int32_t lnode = 0, first = 0, cnt = 0;
+        int lslot = 0;
+        if (!wwalk_next_leaf(W, k, ray, wr, 0.0, INFINITY, lnode, lslot, first, cnt)) break;
+        bool term = false;
+        double lmin[3], lmax[3];
+        W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
+        for (int32_t base = 0; base < cnt; base += 64) {
+            const int32_t j = base + lane;
+            bool ok = false;
+            double u = 0, v = 0, d2 = INFINITY;
+            V3 hp = v3(0, 0, 0);
+            int32_t ti = 0;
+            uint32_t mf = 0;
+            if (j < cnt) {
+                const LeafTri g = S.leaf_tris[first + j];
+                ti = g.tri; mf = g.matflags;
+                ok = ent_hit<FEAT>(g, mf, ray, u, v, hp);
+                if (ok && !(mf & 2u)) {
+                    const Mat& m = S.mats[mf >> 3];
+                    ok = rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < m.opacity * 1.0 || m.ior != 1;
+                }
+                if (ok) d2 = len2(hp - ray.o);
+            }
+            double pm = ok ? d2 : INFINITY;   // inclusive prefix minimum over the lanes
+            for (int off = 1; off < 64; off <<= 1) {
+                const double t = __shfl_up(pm, (unsigned)off);
+                if (lane >= off) pm = fmin(pm, t);
+            }
+            double ex = __shfl_up(pm, 1u);
+            if (lane == 0) ex = INFINITY;
+            if (intersected) ex = fmin(ex, best_d2);
+            const bool take = ok && d2 < ex;
+            const unsigned long long tm = __ballot(take);
+            if (tm != 0ull) {
+                if (__ballot(take && box_contains(lmin, lmax, hp)) != 0ull) term = true;
+                const int last = 63 - __clzll((long long)tm);
+                best.pos = v3(__shfl(hp.x, last), __shfl(hp.y, last), __shfl(hp.z, last));
+                best.u = __shfl(u, last); best.v = __shfl(v, last);
+                best.tri = __shfl(ti, last); best.mf = (uint32_t)__shfl((int)mf, last);
+                best_d2 = __shfl(d2, last);
+                intersected = true;
+            }
+        }
+        if (term) break;
+    }
+    return intersected;
+    }
+}
+template <int FEAT, class WN>
+__device__ __forceinline__ bool visible_wide_coop(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index)
+{
+    if constexpr ((FEAT & GI_FEAT_TEX) != 0) return visible_wide<FEAT>(S, W, ray, mt, rng, light_index);
+    else {
+    const int lane = (int)(threadIdx.x & 63u);
+    const WRay wr = wray_make(ray);
+    const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
+    WWalk k;
+    if (wwalk_begin(S, W, k, ray, wr, 0.0, tmax)) {
+        for (;;) {
+            int32_t lnode = 0, first = 0, cnt = 0;
+            int lslot = 0;
+            if (!wwalk_next_leaf(W, k, ray, wr, 0.0, tmax, lnode, lslot, first, cnt)) break;
+            for (int32_t base = 0; base < cnt; base += 64) {
+                const int32_t j = base + lane;
+                bool blocks = false;
+                if (j < cnt) {
+                    const LeafTri g = S.leaf_tris[first + j];
+                    double u, v;
+                    V3 hp;
+                    bool ok = ent_hit<FEAT>(g, g.matflags, ray, u, v, hp);
+                    if (ok && !(g.matflags & 2u)) {
+                        const Mat& m = S.mats[g.matflags >> 3];
+                        ok = rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)g.tri) < m.opacity * 1.0 || m.ior != 1;
+                    }
+                    if (ok) { const double ts = len2(hp - ray.o); blocks = (ts < mt) && (ts > 0); }
+                }
+                if (__ballot(blocks) != 0ull) return false;
+            }
+        }
+    }
+    if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:308-316
+        double tmin = 0, tmx = mt;
+        if (atmosphere_bounds(S, ray, tmin, tmx)) {
+            V3 fh, fc;
+            if (raymarch(S, ray, fh, fc, tmin, tmx, rng, P_FOG_SHADOW + 16u * light_index)) return false;
+        }
+    }
+    return true;
+    }
+}
+#else
+template <int FEAT, class WN> bool trace_wide_coop(const Scene&, const WN&, const Ray&, const Rng&, uint32_t, HitRec&) { return false; }        // host builds never
+template <int FEAT, class WN> bool visible_wide_coop(const Scene&, const WN&, const Ray&, double, const Rng&, uint32_t) { return false; }    // select kCoop sources
+#endif
+
 // RayTracer::trace.  Leaves are met in the order the reference's t0-sorted list has them because the hit/skip links of a
 // direction octant visit the children of every node front to back; the walk stops after the first leaf that contains a new
 // nearest hit.  Control flow is "while-while": an inner loop walks nodes until THIS lane stands on a non-empty leaf, then the
@@ -753,7 +867,10 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
 template <int FEAT, class Nodes>
 GI_HD bool trace_nodes(const Scene& S, const Nodes& N, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best, Counters* c)
 {
-    if constexpr (Nodes::kWide) return trace_wide<FEAT>(S, N, ray, rng, alpha_purpose, best);
+    if constexpr (Nodes::kWide) {
+        if constexpr (Nodes::kCoop) return trace_wide_coop<FEAT>(S, N, ray, rng, alpha_purpose, best);
+        else return trace_wide<FEAT>(S, N, ray, rng, alpha_purpose, best);
+    }
     else {
     const int oct = dir_octant(ray);
     bool intersected = false;
@@ -830,7 +947,10 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
 template <int FEAT, class Nodes>
 GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
-    if constexpr (Nodes::kWide) return visible_wide<FEAT>(S, N, ray, mt, rng, light_index);
+    if constexpr (Nodes::kWide) {
+        if constexpr (Nodes::kCoop) return visible_wide_coop<FEAT>(S, N, ray, mt, rng, light_index);
+        else return visible_wide<FEAT>(S, N, ray, mt, rng, light_index);
+    }
     else {
     const int oct = dir_octant(ray);
     const double tmax = sqrt(mt) - GI_SHADOW_BIAS;

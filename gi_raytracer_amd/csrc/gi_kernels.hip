@@ -116,6 +116,7 @@ __device__ __forceinline__ LdsNodes stage_nodes_in_lds(const Scene& S)
 #define GI_LDS_WNODES 292                     // 64 KB of 224-byte records
 struct LdsWide {
     static constexpr bool kWide = true;
+    static constexpr bool kCoop = false;
     const WNode* g;
     int32_t n_l;
     template <class F> __device__ __forceinline__ auto with(int32_t i, F&& f) const
@@ -124,6 +125,7 @@ struct LdsWide {
         return f(g + i);
     }
 };
+struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; };   // the same records, one ray per wave (gi_device.h: trace_wide_coop)
 __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S)
 {
     LdsWide N;
@@ -570,6 +572,35 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
     const uint32_t n_in = n_in_dev ? *n_in_dev : n_in_host;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    if constexpr (WIDE != 0) {
+        // few enough paths for one wave each: all 64 lanes work on the same path, a leaf's triangles tested side by side
+        if (lanes <= 0 && n_in <= 2u * n_waves) {
+            LdsWideCoop NC;
+            NC.g = N.g; NC.n_l = N.n_l;
+            for (uint32_t i = wave; i < n_in; i += n_waves) {
+                const uint32_t slot = q_in[i];
+                PathRec p = pool[slot];
+                bool alive = true;
+                for (int b = 0;;) {
+                    if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; break; }
+                    const int fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
+                    if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_FINISH_BLOCK, nullptr);
+                    if (!(fl & ST_CONTINUE)) { alive = false; break; }
+                    if (++b >= max_bounces) break;
+                }
+                if (lane == 0) {
+                    if (alive) {
+                        pool[slot] = p;
+                        q_out[atomicAdd(n_out, 1u)] = slot;
+                    } else {
+                        const unsigned long long id = slot_sample[slot] - sample0;
+                        lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
+                    }
+                }
+            }
+            return;
+        }
+    }
     if (lanes <= 0) lanes = (int)min(64u, max(1u, (n_in + n_waves - 1) / n_waves));   // spread the paths evenly over the resident waves
     if (lane >= (uint32_t)lanes) return;
     for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
