@@ -565,7 +565,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
 template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                         const uint32_t* q_in, const unsigned int* n_in_dev, uint32_t n_in_host, int lanes, int max_bounces,
-                                                        uint32_t* q_out, unsigned int* n_out, double* lbuf)
+                                                        uint32_t* q_out, unsigned int* n_out, double* lbuf, uint32_t coop_factor)
 {
     __shared__ float heap[GI_GATHER_K * GI_FINISH_BLOCK];
     const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // a lone path's bounce is a chain of dependent node reads: LDS, not L2
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     if constexpr (WIDE != 0) {
         // few enough paths for one wave each: all 64 lanes work on the same path, a leaf's triangles tested side by side
-        if (lanes <= 0 && n_in <= 2u * n_waves) {
+        if (lanes <= 0 && n_in <= coop_factor * n_waves) {
             LdsWideCoop NC;
             NC.g = N.g; NC.n_l = N.n_l;
             for (uint32_t i = wave; i < n_in; i += n_waves) {
@@ -817,6 +817,7 @@ struct gi_ctx {
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
     size_t pool_slots_max = (size_t)1 << 30;    // upper bound on paths in flight; the actual pool is also bounded by free HBM (render_streaming)
     uint32_t finish_threshold = 1u << 17;
+    uint32_t coop_factor = 8;         // finisher stages with at most coop_factor x (resident waves) paths run one path per wave
     // finisher stages {paths per wave (0: spread evenly over the resident waves), max vertices}; the last stage runs to MAX_DEPTH.
     // Measured on the default frame (tools/stripe_probe.py): one full-wave stage 60 ms, this plan 51 ms; on 1/8 of the rows 40 -> 30 ms.
     std::vector<std::pair<int, int>> finish_plan = {{0, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 4}, {0, 8}, {0, GI_MAX_DEPTH + 1}};
@@ -868,6 +869,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     }
     c->S.hdims = c->d_hdims.p;
     c->S.htable = c->d_htable.p;
+    if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
     if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."
         std::vector<std::pair<int, int>> plan;
@@ -1181,7 +1183,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
                     const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
                     stage_begin(c, STG_FINISH);
                     hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1> : k_st_finish<7, 0>) : wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(g_finish), dim3(GI_FINISH_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
-                                       fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, c->d_lbuf.p);
+                                       fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, c->d_lbuf.p, c->coop_factor);
                     stage_end(c);
                     launches++;
                     uint32_t* t = const_cast<uint32_t*>(fq_in); fq_in = fq_out; fq_out = t;   // both are this chunk's continuation queues
