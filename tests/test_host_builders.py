@@ -69,7 +69,7 @@ def test_bad_inputs_fail_loudly(tmp_path):
     scn = tmp_path / "t.scn"
     scn.write_text("imTex a.png 1 1\n")
     with pytest.raises(gi.GiError):
-        gi.Scene.load(str(scn))                    # image textures are out of scope: refuse instead of guessing
+        gi.Scene.load(str(scn))                    # the image file does not exist: refuse instead of guessing a colour
 
 
 def test_pfm_and_ppm_writers(tmp_path):
@@ -86,3 +86,71 @@ def test_pfm_and_ppm_writers(tmp_path):
     px = np.frombuffer(raw[len(b"P6\n7 5\n255\n"):], np.uint8).reshape(5, 7, 3)
     want = (255 * np.clip(lin.astype(np.float64) ** (1 / 2.2), 0, 1)).astype(np.int32)
     assert np.array_equal(px, want) and px.max() == 255
+
+
+def test_png_decoder_matches_pil_on_every_supported_colour_type(tmp_path):
+    """gih_load_png (the `imTex` loader): grey, RGB, palette (+tRNS), grey+alpha, RGBA, every scanline filter, against PIL's decode;
+    16-bit and interlaced files are refused by name."""
+    import ctypes as C
+    from PIL import Image
+    import gi_raytracer_amd as gi
+    L = gi.lib()
+    rs = np.random.RandomState(7)
+
+    def load(path):
+        w, h, a = C.c_int32(), C.c_int32(), C.c_int32()
+        px = C.POINTER(C.c_uint8)()
+        err = C.create_string_buffer(256)
+        rc = L.gih_load_png(str(path).encode(), C.byref(w), C.byref(h), C.byref(a), C.byref(px), err, 256)
+        if rc != 0:
+            return rc, err.value.decode(), None, None
+        arr = np.ctypeslib.as_array(px, (h.value, w.value, 4)).copy()
+        L.gih_free(px)
+        return 0, "", arr, a.value
+
+    smooth = (np.add.outer(np.arange(37), np.arange(53)) * 3 % 256).astype(np.uint8)      # gradients make the encoder pick several filters
+    cases = {
+        "L": Image.fromarray(smooth, "L"),
+        "RGB": Image.fromarray(np.stack([smooth, 255 - smooth, rs.randint(0, 256, smooth.shape).astype(np.uint8)], -1), "RGB"),
+        "LA": Image.fromarray(np.stack([smooth, 255 - smooth], -1), "LA"),
+        "RGBA": Image.fromarray(rs.randint(0, 256, (37, 53, 4)).astype(np.uint8), "RGBA"),
+        "P": Image.fromarray(rs.randint(0, 256, (37, 53, 3)).astype(np.uint8), "RGB").convert("P", palette=Image.ADAPTIVE, colors=64),
+    }
+    for name, im in cases.items():
+        path = tmp_path / (name + ".png")
+        im.save(path)
+        rc, err, arr, alpha = load(path)
+        assert rc == 0, (name, err)
+        assert np.array_equal(arr, np.array(im.convert("RGBA"))), name
+        assert alpha == (1 if name in ("LA", "RGBA") else 0), name
+    pal = cases["P"].copy()
+    pal.info["transparency"] = 3
+    pal.save(tmp_path / "ptrns.png", transparency=3)
+    rc, err, arr, alpha = load(tmp_path / "ptrns.png")
+    assert rc == 0 and alpha == 1 and np.array_equal(arr, np.array(Image.open(tmp_path / "ptrns.png").convert("RGBA")))
+    Image.fromarray((rs.rand(8, 8) * 65535).astype(np.uint16)).save(tmp_path / "deep.png")
+    rc, err, _, _ = load(tmp_path / "deep.png")
+    assert rc != 0 and "8 bits" in err
+    rc, err, _, _ = load(tmp_path / "missing.png")
+    assert rc != 0 and "cannot open" in err
+
+
+def test_texture_tables_are_validated(golden):
+    """gi_upload_scene's checks of the texture tables (run here through the CPU build of the same layout code)."""
+    import ctypes as C
+    import gi_raytracer_amd as gi
+    import emul_lib as el
+    import parity_checks as pc
+    scene = pc.load_scene("textures")
+    rt = el.EmulRayTracer()
+    d = scene.desc()
+    assert rt.E.emul_upload_scene(rt.h, C.byref(d)) == 0
+    mt = np.ctypeslib.as_array(d.mat_tex, (d.n_mat * 2,)).copy()
+    bad = mt.copy(); bad[1] = d.n_tex
+    d2 = scene.desc(); d2.mat_tex = bad.ctypes.data_as(gi._ip)
+    assert rt.E.emul_upload_scene(rt.h, C.byref(d2)) != 0 and b"texture index" in rt.E.emul_error(rt.h)
+    d3 = scene.desc(); d3.n_tex_pixel_bytes = 16
+    assert rt.E.emul_upload_scene(rt.h, C.byref(d3)) != 0 and b"pixel table" in rt.E.emul_error(rt.h)
+    kinds = np.ctypeslib.as_array(d.tex_kind, (d.n_tex,)).copy(); kinds[0] = 9
+    d4 = scene.desc(); d4.tex_kind = kinds.ctypes.data_as(gi._ip)
+    assert rt.E.emul_upload_scene(rt.h, C.byref(d4)) != 0 and b"texture kind" in rt.E.emul_error(rt.h)
