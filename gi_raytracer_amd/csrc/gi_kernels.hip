@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -292,6 +293,74 @@ __global__ __launch_bounds__(GI_BLOCK) void k_wf_accum(Frame F, PixRec* pix, con
             PixelState ps;
             ps.color = ld3(r.color); ps.lastCol = ld3(r.lastCol); ps.var = r.var; ps.samps = r.samps; ps.s = r.s;
             for (int k = 0; k < r.n; k++) pixel_add_sample(ps, F, ld3(pool[(size_t)i * B + k].L));
+            r.color[0] = ps.color.x; r.color[1] = ps.color.y; r.color[2] = ps.color.z;
+            r.lastCol[0] = ps.lastCol.x; r.lastCol[1] = ps.lastCol.y; r.lastCol[2] = ps.lastCol.z;
+            r.var = ps.var; r.samps = ps.samps; r.s = ps.s; r.n = 0;
+            pix[i] = r;
+            wants = pixel_wants_sample(ps, F);
+            const size_t o = ((size_t)ly * F.w + x);
+            if (out_f64) {
+                double* p = (double*)out + o * 3;
+                p[0] = ps.color.x; p[1] = ps.color.y; p[2] = ps.color.z;
+            } else {
+                float* p = (float*)out + o * 3;
+                p[0] = (float)ps.color.x; p[1] = (float)ps.color.y; p[2] = (float)ps.color.z;
+            }
+            if (out_spp) out_spp[o] = ps.s;
+        }
+        (void)wave_append(n_wanting, wants);
+    }
+}
+
+// Adaptive rounds on the streaming machinery (render_adaptive): the paths of a round are started here, compacted into q_new, and then
+// go through the k_st_* passes; a finished path leaves its radiance in lbuf[slot] (slot_sample[slot] = slot), which the accumulate
+// step folds into the pixel in sample order.
+__global__ __launch_bounds__(GI_BLOCK) void k_ad_gen(Scene S, Frame F, PixRec* pix, PathRec* pool, unsigned long long* slot_sample, uint32_t n_pix, int B,
+                                                    uint32_t* q_new, unsigned int* n_new)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_round = (n_pix + 63u) & ~63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_round; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        int x = 0, ly = 0, n = 0, s0 = 0;
+        const bool inside = i < n_pix && wf_pixel_xy(F, i, x, ly);
+        if (inside) {
+            const int s = pix[i].s, samps = pix[i].samps;
+            if (s < F.max_samples && samps < F.min_samples) {
+                n = min(B, min(F.max_samples - s, F.min_samples - samps));   // samples this pixel takes for certain (include/raytracer.h:143-147)
+                s0 = s;
+            }
+            pix[i].n = n;
+        }
+        const int y = inside ? global_row(F, ly) : 0;
+        for (int k = 0; k < B; k++) {                       // wave-uniform trip count: the appends below are collective
+            const bool start = k < n;
+            const uint32_t slot = i * (uint32_t)B + (uint32_t)k;
+            if (start) {
+                uint32_t idx;
+                Ray ray = primary_ray(S, F, s0 + k, x, y, idx);
+                path_begin_lean(pool[slot], ray, idx);
+                slot_sample[slot] = slot;
+            }
+            const uint32_t at = wave_append(n_new, start);
+            if (start) q_new[at] = slot;
+        }
+    }
+}
+__global__ __launch_bounds__(GI_BLOCK) void k_ad_accum(Frame F, PixRec* pix, const double* lbuf, uint32_t n_pix, int B, void* out, int out_f64,
+                                                      int32_t* out_spp, unsigned int* n_wanting)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_round = (n_pix + 63u) & ~63u;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_round; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + lane;
+        bool wants = false;
+        int x, ly;
+        if (i < n_pix && wf_pixel_xy(F, i, x, ly)) {
+            PixRec r = pix[i];
+            PixelState ps;
+            ps.color = ld3(r.color); ps.lastCol = ld3(r.lastCol); ps.var = r.var; ps.samps = r.samps; ps.s = r.s;
+            for (int k = 0; k < r.n; k++) pixel_add_sample(ps, F, ld3(lbuf + ((size_t)i * B + k) * 3));
             r.color[0] = ps.color.x; r.color[1] = ps.color.y; r.color[2] = ps.color.z;
             r.lastCol[0] = ps.lastCol.x; r.lastCol[1] = ps.lastCol.y; r.lastCol[2] = ps.lastCol.z;
             r.var = ps.var; r.samps = ps.samps; r.s = ps.s; r.n = 0;
@@ -1090,6 +1159,120 @@ static void stage_end(gi_ctx* c)
     c->ev_used += 2;
 }
 
+struct StreamGrids { int init = 0, regen = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0; };
+static const size_t kLdsNodes = (size_t)GI_LDS_NODES * sizeof(TNode);
+static const StreamGrids& stream_grids(gi_ctx* c)
+{
+    static StreamGrids g;
+    if (!g.trace) {
+        g.init = grid_for(c, (const void*)k_wf_init); g.regen = grid_for(c, (const void*)k_st_regen); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
+        g.shade = grid_for(c, (const void*)k_st_shade<7, 1>, kLdsNodes, GI_SHADE_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
+        g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
+    }
+    return g;
+}
+// everything the pass loop needs for P paths in flight (the radiance buffer is the caller's)
+static int stream_alloc(gi_ctx* c, uint32_t P)
+{
+    if (c->d_pool.n < P) HIP_TRY(c, c->d_pool.alloc(P));
+    if (c->d_slot_sample.n < P) HIP_TRY(c, c->d_slot_sample.alloc(P));
+    for (int k = 0; k < 6; k++) if (c->d_qs[k].n < P) HIP_TRY(c, c->d_qs[k].alloc(P));
+    if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
+    for (int k = 0; k < 2; k++) { if (c->d_gk[k].n < P) HIP_TRY(c, c->d_gk[k].alloc(P)); if (c->d_gv[k].n < P) HIP_TRY(c, c->d_gv[k].alloc(P)); }
+    for (int k = 0; k < 2; k++) if (c->d_ck[k].n < P) HIP_TRY(c, c->d_ck[k].alloc(P));
+    if (c->d_cv.n < P) HIP_TRY(c, c->d_cv.alloc(P));
+    {
+        size_t need = 0;
+        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0, 32, c->stream));
+        if (c->d_sort_tmp.n < need) HIP_TRY(c, c->d_sort_tmp.alloc(need));
+    }
+    if (!c->d_ctl.p) HIP_TRY(c, c->d_ctl.alloc(1));
+    if (!c->h_ctl) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, sizeof(StreamCtl), hipHostMallocDefault));
+    return GI_OK;
+}
+// The pass loop: trace -> shade -> (keys, sort, gather) -> sort of the continuing rays, until nothing is in flight.  refill(n_free, qf)
+// starts up to n_free new paths in the slots of the free list qf (nullptr: slots 0 .. n_free - 1), writes them to c->d_qs[0] and
+// returns how many; `exhausted` tells that it will start no more.  A finished path leaves its radiance at lbuf[slot_sample[slot] - sample0].
+static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, double* lbuf, uint32_t n_free,
+                         const std::function<uint32_t(uint32_t, const uint32_t*)>& refill, const bool& exhausted,
+                         volatile const int* cancel, int& launches)
+{
+    const StreamGrids& G = stream_grids(c);
+    hipStream_t st = c->stream;
+    const bool wide = c->S.wnodes != nullptr;
+    PathRec* pool = c->d_pool.p;
+    StreamCtl* ctl = c->d_ctl.p;
+    uint32_t* q_new = c->d_qs[0].p;
+    uint32_t* q_cont[2] = {c->d_qs[1].p, c->d_qs[2].p};
+    uint32_t* q_shade = c->d_qs[3].p;
+    uint32_t* q_gather = c->d_qs[4].p;
+    uint32_t* q_free[2] = {c->d_qs[5].p, c->d_q[0].p};
+    uint32_t n_cont = 0;
+    const uint32_t* qf = nullptr;
+    int ping = 0;
+    for (;;) {
+        if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
+        const uint32_t n_new = refill(n_free, qf);
+        if (n_new + n_cont == 0) break;
+        uint32_t* qcont_out = q_cont[ping];
+        const uint32_t* qcont_in = q_cont[ping ^ 1];
+        if (exhausted && n_new == 0 && n_cont <= c->finish_threshold) {
+            const bool sphf = c->S.has_spheres != 0, fogf = c->S.n_fog > 0, texf = c->S.n_tex > 0;
+            if (c->d_fin_cnt.n < 16) HIP_TRY(c, c->d_fin_cnt.alloc(16));
+            HIP_TRY(c, hipMemsetAsync(c->d_fin_cnt.p, 0, 16 * sizeof(unsigned int), st));
+            const uint32_t* fq_in = qcont_in;
+            uint32_t* fq_out = qcont_out;
+            const size_t n_stage = std::min<size_t>(c->finish_plan.size(), 15);
+            for (size_t k = 0; k < n_stage; k++) {
+                const int lanes = c->finish_plan[k].first, vertices = k + 1 == n_stage ? GI_MAX_DEPTH + 1 : c->finish_plan[k].second;
+                const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
+                stage_begin(c, STG_FINISH);
+                hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1> : k_st_finish<7, 0>) : wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(G.finish), dim3(GI_FINISH_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
+                                   fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, lbuf, c->coop_factor);
+                stage_end(c);
+                launches++;
+                uint32_t* t = const_cast<uint32_t*>(fq_in); fq_in = fq_out; fq_out = t;   // both are this chunk's continuation queues
+            }
+            break;
+        }
+        HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
+        uint32_t* qfree_out = q_free[ping];
+        const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0, tex = c->S.n_tex > 0;
+        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+                           q_shade, qfree_out, lbuf); stage_end(c);
+        stage_begin(c, STG_SHADE); hipLaunchKernelGGL(tex ? (wide ? k_st_shade<7, 1> : k_st_shade<7, 0>) : wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
+                           qfree_out, lbuf); stage_end(c);
+        launches += 2;
+        HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const uint32_t n_gather = c->h_ctl->n_gather;
+        if (c->S.n_pnode > 0 && n_gather > 0) {
+            int bits = 1;
+            while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
+            stage_begin(c, STG_SORT); hipLaunchKernelGGL(k_st_gkeys, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p); stage_end(c);
+            size_t tmp_bytes = c->d_sort_tmp.n;
+            stage_begin(c, STG_SORT);
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
+            stage_end(c);
+            stage_begin(c, STG_GATHER); hipLaunchKernelGGL(k_st_gather, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather); stage_end(c);
+            launches += 3;
+        }
+        n_cont = c->h_ctl->n_cont;
+        n_free = c->h_ctl->n_free;
+        if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
+            size_t tmp_bytes = c->d_sort_tmp.n;
+            stage_begin(c, STG_SORT);
+            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, 0, 27, st));
+            stage_end(c);
+            launches++;
+        }
+        qf = qfree_out;
+        ping ^= 1;
+        if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u\n", n_new, n_cont, n_free, n_gather);
+    }
+    return GI_OK;
+}
+
 static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
 {
     const uint32_t n_pix = (uint32_t)F.w * (uint32_t)F.local_rows;   // valid pixels only, enumerated in 8x8-tile order (st_pixel_xy)
@@ -1110,123 +1293,95 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     }
     const uint32_t P = (uint32_t)std::max<size_t>(64, std::min<size_t>(std::min<size_t>(slots_budget, 0xfffffff0u), (size_t)n_pix * (size_t)spp));
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)));
-    if (c->d_pool.n < P) HIP_TRY(c, c->d_pool.alloc(P));
-    if (c->d_slot_sample.n < P) HIP_TRY(c, c->d_slot_sample.alloc(P));
+    int rc = stream_alloc(c, P);
+    if (rc) return rc;
     if (c->d_pix.n < n_pix) HIP_TRY(c, c->d_pix.alloc(n_pix));
-    for (int k = 0; k < 6; k++) if (c->d_qs[k].n < P) HIP_TRY(c, c->d_qs[k].alloc(P));
-    if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
     if (c->d_lbuf.n < (size_t)n_pix * chunk * 3) HIP_TRY(c, c->d_lbuf.alloc((size_t)n_pix * chunk * 3));
-    for (int k = 0; k < 2; k++) { if (c->d_gk[k].n < P) HIP_TRY(c, c->d_gk[k].alloc(P)); if (c->d_gv[k].n < P) HIP_TRY(c, c->d_gv[k].alloc(P)); }
-    for (int k = 0; k < 2; k++) if (c->d_ck[k].n < P) HIP_TRY(c, c->d_ck[k].alloc(P));
-    if (c->d_cv.n < P) HIP_TRY(c, c->d_cv.alloc(P));
-    {
-        size_t need = 0;
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0, 32, c->stream));
-        if (c->d_sort_tmp.n < need) HIP_TRY(c, c->d_sort_tmp.alloc(need));
-    }
-    if (!c->d_ctl.p) HIP_TRY(c, c->d_ctl.alloc(1));
-    if (!c->h_ctl) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, sizeof(StreamCtl), hipHostMallocDefault));
-    static int g_init = 0, g_regen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0, g_finish = 0;
-    const size_t lds_nodes = (size_t)GI_LDS_NODES * sizeof(TNode);
-    if (!g_trace) {
-        g_init = grid_for(c, (const void*)k_wf_init); g_regen = grid_for(c, (const void*)k_st_regen); g_trace = grid_for(c, (const void*)k_st_trace<7, 1>, lds_nodes, GI_TRACE_BLOCK);
-        g_shade = grid_for(c, (const void*)k_st_shade<7, 1>, lds_nodes, GI_SHADE_BLOCK); g_gather = grid_for(c, (const void*)k_st_gather); g_accum = grid_for(c, (const void*)k_st_accum); g_finish = grid_for(c, (const void*)k_st_finish<7, 1>, lds_nodes, GI_FINISH_BLOCK);
-    }
+    const StreamGrids& G = stream_grids(c);
     hipStream_t st = c->stream;
-    const bool wide = c->S.wnodes != nullptr;
-    PathRec* pool = c->d_pool.p;
-    StreamCtl* ctl = c->d_ctl.p;
-    uint32_t* q_new = c->d_qs[0].p;
-    uint32_t* q_cont[2] = {c->d_qs[1].p, c->d_qs[2].p};
-    uint32_t* q_shade = c->d_qs[3].p;
-    uint32_t* q_gather = c->d_qs[4].p;
-    uint32_t* q_free[2] = {c->d_qs[5].p, c->d_q[0].p};
     int launches = 0;
     c->ev_used = 0; c->ev_stage.clear();
     HIP_TRY(c, hipEventRecord(c->ev0, st));
-    hipLaunchKernelGGL(k_wf_init, dim3(g_init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
+    hipLaunchKernelGGL(k_wf_init, dim3(G.init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
     launches++;
     for (int s0 = 0; s0 < spp; s0 += chunk) {
         const int ns = std::min(chunk, spp - s0);
         const unsigned long long sample0 = (unsigned long long)s0 * n_pix, sample_end = (unsigned long long)(s0 + ns) * n_pix;
-        StreamCtl h0;
-        memset(&h0, 0, sizeof h0);
-        h0.next_sample = sample0;
-        *c->h_ctl = h0;
-        HIP_TRY(c, hipMemcpyAsync(ctl, c->h_ctl, sizeof(StreamCtl), hipMemcpyHostToDevice, st));
-        HIP_TRY(c, hipStreamSynchronize(st));
-        // pass 0: every slot is free
-        uint32_t n_free = P, n_cont = 0;
         unsigned long long next = sample0;
-        const uint32_t* qf = nullptr;
-        int ping = 0;
-        for (;;) {
-            if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
+        bool exhausted = false;
+        auto refill = [&](uint32_t n_free, const uint32_t* qf) -> uint32_t {   // path regeneration: free slots take the next samples
             const uint32_t n_new = (uint32_t)std::min<unsigned long long>(n_free, sample_end - next);
             if (n_new > 0) {
-                stage_begin(c, STG_REGEN); hipLaunchKernelGGL(k_st_regen, dim3(g_regen), dim3(GI_BLOCK), 0, st, c->S, F, pool, c->d_slot_sample.p, qf, n_new, next, sample0, s0, n_pix, q_new); stage_end(c);
+                stage_begin(c, STG_REGEN); hipLaunchKernelGGL(k_st_regen, dim3(G.regen), dim3(GI_BLOCK), 0, st, c->S, F, c->d_pool.p, c->d_slot_sample.p, qf, n_new, next, sample0, s0, n_pix, c->d_qs[0].p); stage_end(c);
                 launches++;
                 next += n_new;
             }
-            if (n_new + n_cont == 0) break;
-            uint32_t* qcont_out = q_cont[ping];
-            const uint32_t* qcont_in = q_cont[ping ^ 1];
-            if (next >= sample_end && n_new == 0 && n_cont <= c->finish_threshold) {
-                const bool sphf = c->S.has_spheres != 0, fogf = c->S.n_fog > 0, texf = c->S.n_tex > 0;
-                if (c->d_fin_cnt.n < 16) HIP_TRY(c, c->d_fin_cnt.alloc(16));
-                HIP_TRY(c, hipMemsetAsync(c->d_fin_cnt.p, 0, 16 * sizeof(unsigned int), st));
-                const uint32_t* fq_in = qcont_in;
-                uint32_t* fq_out = qcont_out;
-                const size_t n_stage = std::min<size_t>(c->finish_plan.size(), 15);
-                for (size_t k = 0; k < n_stage; k++) {
-                    const int lanes = c->finish_plan[k].first, vertices = k + 1 == n_stage ? GI_MAX_DEPTH + 1 : c->finish_plan[k].second;
-                    const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
-                    stage_begin(c, STG_FINISH);
-                    hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1> : k_st_finish<7, 0>) : wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(g_finish), dim3(GI_FINISH_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
-                                       fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, c->d_lbuf.p, c->coop_factor);
-                    stage_end(c);
-                    launches++;
-                    uint32_t* t = const_cast<uint32_t*>(fq_in); fq_in = fq_out; fq_out = t;   // both are this chunk's continuation queues
-                }
-                break;
-            }
-            HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
-            uint32_t* qfree_out = q_free[ping];
-            const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0, tex = c->S.n_tex > 0;
-            stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(g_trace), dim3(GI_TRACE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
-                               q_shade, qfree_out, c->d_lbuf.p); stage_end(c);
-            stage_begin(c, STG_SHADE); hipLaunchKernelGGL(tex ? (wide ? k_st_shade<7, 1> : k_st_shade<7, 0>) : wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(g_shade), dim3(GI_SHADE_BLOCK), lds_nodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
-                               qfree_out, c->d_lbuf.p); stage_end(c);
-            launches += 2;
-            HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-            const uint32_t n_gather = c->h_ctl->n_gather;
-            if (c->S.n_pnode > 0 && n_gather > 0) {
-                int bits = 1;
-                while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
-                stage_begin(c, STG_SORT); hipLaunchKernelGGL(k_st_gkeys, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p); stage_end(c);
-                size_t tmp_bytes = c->d_sort_tmp.n;
-                stage_begin(c, STG_SORT);
-                HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
-                stage_end(c);
-                stage_begin(c, STG_GATHER); hipLaunchKernelGGL(k_st_gather, dim3(g_gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather); stage_end(c);
-                launches += 3;
-            }
-            n_cont = c->h_ctl->n_cont;
-            n_free = c->h_ctl->n_free;
-            if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
-                size_t tmp_bytes = c->d_sort_tmp.n;
-                stage_begin(c, STG_SORT);
-                HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, 0, 27, st));
-                stage_end(c);
-                launches++;
-            }
-            qf = qfree_out;
-            ping ^= 1;
-            if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u next %llu/%llu\n", n_new, n_cont, n_free, n_gather, next, sample_end);
-        }
-        stage_begin(c, STG_ACCUM); hipLaunchKernelGGL(k_st_accum, dim3(g_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, ns, d_out, out_is_f64, d_spp); stage_end(c);
+            exhausted = next >= sample_end;
+            return n_new;
+        };
+        rc = stream_passes(c, F, sample0, c->d_lbuf.p, P, refill, exhausted, cancel, launches);   // pass 0: every slot is free
+        if (rc) return rc;
+        stage_begin(c, STG_ACCUM); hipLaunchKernelGGL(k_st_accum, dim3(G.accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, ns, d_out, out_is_f64, d_spp); stage_end(c);
         launches++;
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev1, st));
+    c->last_launches = launches;
+    return GI_OK;
+}
+
+// Adaptive sampling (min_samples != max_samples, include/raytracer.h:108-148): rounds as in render_wavefront -- a pixel starts the
+// samples it is certain to take, the variance rule is applied in sample order -- but the paths of a round run through the streaming
+// passes (sorted queues, octree records in LDS, wave-cooperative gather, staged finisher) instead of one generic kernel per depth.
+static int render_adaptive(gi_ctx* c, const Frame& F, void* d_out, int out_is_f64, int32_t* d_spp, volatile const int* cancel)
+{
+    const uint32_t tiles = (uint32_t)(((F.w + 7) >> 3) * ((F.local_rows + 7) >> 3));
+    const uint32_t n_pix = tiles * 64u;   // padded to whole 8x8 tiles (wf_pixel_xy)
+    int B = (int)std::min<size_t>(32, std::max<size_t>(1, c->pool_slots_max / n_pix));
+    B = std::max(1, std::min(B, std::max(F.max_samples, 1)));
+    const size_t slots = (size_t)n_pix * (size_t)B;
+    if (slots > 0xfffffff0ull) return fail(c, GI_E_INVALID, "render: frame too large for 32-bit path slots");
+    int rc = stream_alloc(c, (uint32_t)slots);
+    if (rc) return rc;
+    if (c->d_pix.n < n_pix) HIP_TRY(c, c->d_pix.alloc(n_pix));
+    if (c->d_lbuf.n < slots * 3) HIP_TRY(c, c->d_lbuf.alloc(slots * 3));
+    if (!c->d_wfcnt.p) HIP_TRY(c, c->d_wfcnt.alloc(4));
+    if (!c->h_wfcnt) HIP_TRY(c, hipHostMalloc((void**)&c->h_wfcnt, 4 * sizeof(unsigned int), hipHostMallocDefault));
+    const StreamGrids& G = stream_grids(c);
+    hipStream_t st = c->stream;
+    unsigned int* cnt = c->d_wfcnt.p;
+    int launches = 0;
+    c->ev_used = 0; c->ev_stage.clear();
+    HIP_TRY(c, hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(k_wf_init, dim3(G.init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
+    launches++;
+    bool any = F.max_samples > 0 && F.min_samples > 0;
+    if (!any) {   // 0 samples per pixel still has to write the initial colour
+        HIP_TRY(c, hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_ad_accum, dim3(G.ad_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, B, d_out, out_is_f64, d_spp, cnt + 3);
+        launches++;
+    }
+    while (any) {
+        if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
+        HIP_TRY(c, hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned int), st));
+        stage_begin(c, STG_REGEN);
+        hipLaunchKernelGGL(k_ad_gen, dim3(G.ad_gen), dim3(GI_BLOCK), 0, st, c->S, F, c->d_pix.p, c->d_pool.p, c->d_slot_sample.p, n_pix, B, c->d_qs[0].p, cnt + 0);
+        stage_end(c);
+        launches++;
+        HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        uint32_t pending = c->h_wfcnt[0];          // paths started by this round, already in the new-path queue
+        const bool exhausted = true;
+        auto refill = [&](uint32_t, const uint32_t*) -> uint32_t { const uint32_t n = pending; pending = 0; return n; };
+        rc = stream_passes(c, F, 0ull, c->d_lbuf.p, 0u, refill, exhausted, cancel, launches);
+        if (rc) return rc;
+        stage_begin(c, STG_ACCUM);
+        hipLaunchKernelGGL(k_ad_accum, dim3(G.ad_accum), dim3(GI_BLOCK), 0, st, F, c->d_pix.p, c->d_lbuf.p, n_pix, B, d_out, out_is_f64, d_spp, cnt + 3);
+        stage_end(c);
+        launches++;
+        HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt + 3, cnt + 3, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        any = c->h_wfcnt[3] > 0;
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev1, st));
@@ -1246,8 +1401,10 @@ int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_
     c->last_ms = 0; c->last_launches = 0;
     if (F.local_rows == 0) return GI_OK;
     if (c->render_mode == 1 || c->count_enabled) return render_megakernel(c, F, d_out, out_is_f64, d_spp);
-    // fixed sample count: streaming pool with path regeneration; adaptive sampling: synchronous rounds (sample-order decisions)
+    // fixed sample count: streaming pool with path regeneration; adaptive sampling: rounds (sample-order decisions) on the same passes;
+    // mode 2: the plain per-depth rounds, kept as a second schedule of the same arithmetic
     if (c->render_mode == 0 && F.min_samples == F.max_samples && F.max_samples > 0) return render_streaming(c, F, d_out, out_is_f64, d_spp, cancel);
+    if (c->render_mode == 0) return render_adaptive(c, F, d_out, out_is_f64, d_spp, cancel);
     return render_wavefront(c, F, d_out, out_is_f64, d_spp, cancel);
 }
 
