@@ -327,7 +327,11 @@ __global__ __launch_bounds__(GI_BLOCK) void k_ad_gen(Scene S, Frame F, PixRec* p
         if (inside) {
             const int s = pix[i].s, samps = pix[i].samps;
             if (s < F.max_samples && samps < F.min_samples) {
-                n = min(B, min(F.max_samples - s, F.min_samples - samps));   // samples this pixel takes for certain (include/raytracer.h:143-147)
+                // min - samps samples are certain (each adds 1 to samps or subtracts 1, include/raytracer.h:143-147).  Past those the
+                // pixel may stop at any sample, but which one is decided by the radiances in sample order alone: starting up to B
+                // samples and folding them until the rule says stop (k_ad_accum) takes the same samples in the same order; the
+                // surplus is discarded.  A handful of rounds instead of one per sample of a borderline pixel.
+                n = min(min(B, F.max_samples - s), max(F.min_samples - samps, 8));   // at least the certain ones, at most 8 on speculation
                 s0 = s;
             }
             pix[i].n = n;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_ad_accum(Frame F, PixRec* pix, con
             PixRec r = pix[i];
             PixelState ps;
             ps.color = ld3(r.color); ps.lastCol = ld3(r.lastCol); ps.var = r.var; ps.samps = r.samps; ps.s = r.s;
-            for (int k = 0; k < r.n; k++) pixel_add_sample(ps, F, ld3(lbuf + ((size_t)i * B + k) * 3));
+            for (int k = 0; k < r.n && pixel_wants_sample(ps, F); k++) pixel_add_sample(ps, F, ld3(lbuf + ((size_t)i * B + k) * 3));
             r.color[0] = ps.color.x; r.color[1] = ps.color.y; r.color[2] = ps.color.z;
             r.lastCol[0] = ps.lastCol.x; r.lastCol[1] = ps.lastCol.y; r.lastCol[2] = ps.lastCol.z;
             r.var = ps.var; r.samps = ps.samps; r.s = ps.s; r.n = 0;
