@@ -1119,16 +1119,6 @@ static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
             HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt, cnt, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
             HIP_TRY(c, hipStreamSynchronize(st));
             if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[wf] depth %d in %u shade %u next %u gather %u\n", depth, n_in, c->h_wfcnt[0], c->h_wfcnt[1], c->h_wfcnt[2]);
-            if (getenv("GI_DEBUG_WF") && depth == 40 && c->h_wfcnt[1] > 0) {
-                std::vector<uint32_t> q(std::min<uint32_t>(c->h_wfcnt[1], 12));
-                (void)hipMemcpy(q.data(), q_next, q.size() * 4, hipMemcpyDeviceToHost);
-                for (uint32_t sl : q) {
-                    PathRec r;
-                    (void)hipMemcpy(&r, pool + sl, sizeof r, hipMemcpyDeviceToHost);
-                    fprintf(stderr, "[wf] straggler slot %u o=(%.17g %.17g %.17g) d=(%.17g %.17g %.17g) T=(%g %g %g) contrib=(%g %g %g) tri=%d hpos=(%g %g %g)\n", sl, r.o[0], r.o[1], r.o[2], r.d[0], r.d[1], r.d[2],
-                            r.T[0], r.T[1], r.T[2], r.contrib[0], r.contrib[1], r.contrib[2], r.htri, r.hpos[0], r.hpos[1], r.hpos[2]);
-                }
-            }
             n_in = c->h_wfcnt[1];
             q_in = q_next;
             ping ^= 1;
