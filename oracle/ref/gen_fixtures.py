@@ -26,6 +26,8 @@ SCENES = {
     "spheres": (f"{ROOT}/scenes/spheres/spheres_opaque.scn", 48, 36, 4000),
     # checkerboard and image textures (with and without alpha), on meshes and on spheres; also pins texture::get / getAlpha on a uv lattice
     "textures": (f"{ROOT}/scenes/textures/tex_opaque.scn", 48, 36, 1500),
+    # the reference's second caustics scene: a glass sphere MESH (IOR 1.5, smooth normals), a metal mesh, ambient light
+    "caustics_02": (f"{REF}/scenes/caustics_02/caustics.scn", 64, 48, 6000),
 }
 CHAINS = {
     # name: (scene, W, H, spp, photons, mode)
@@ -42,6 +44,8 @@ CHAINS = {
     "chain_fog_run": (f"{ROOT}/scenes/fog/fog.scn", 40, 30, 4, 1500, "run"),
     "chain_textures_lin": (f"{ROOT}/scenes/textures/tex.scn", 40, 30, 4, 1500, "lin"),
     "chain_textures_run": (f"{ROOT}/scenes/textures/tex.scn", 40, 30, 4, 1500, "run"),
+    "chain_caustics_02_lin": (f"{REF}/scenes/caustics_02/caustics.scn", 40, 30, 4, 2000, "lin"),
+    "chain_caustics_02_run": (f"{REF}/scenes/caustics_02/caustics.scn", 40, 30, 4, 2000, "run"),
 }
 
 

@@ -8,7 +8,7 @@ import gi_raytracer_amd as gi
 import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCN = {"test_scene": "scenes/test_scene/test.scn", "cornell": "scenes/cornell/test.scn", "caustics": "scenes/caustics/caustics.scn",
+SCN = {"test_scene": "scenes/test_scene/test.scn", "cornell": "scenes/cornell/test.scn", "caustics": "scenes/caustics/caustics.scn", "caustics_02": "scenes/caustics_02/caustics.scn",
        "teapot": "scenes/cornell/teapot.scn", "textures": "scenes/textures/tex.scn", "textures_opaque": "scenes/textures/tex_opaque.scn", "cornell_tex": "scenes/textures/cornell_tex.scn", "spheres": "scenes/spheres/spheres.scn", "spheres_opaque": "scenes/spheres/spheres_opaque.scn", "fog": "scenes/fog/fog.scn"}
 
 # float tolerance of the path (north_star: pixel RMSE < 1e-4 on linear radiance); measured values are ~1e-16

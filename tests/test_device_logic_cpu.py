@@ -8,7 +8,7 @@ import emul_lib as el
 import parity_checks as pc
 
 
-@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque", "textures_opaque"])
+@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque", "textures_opaque", "caustics_02"])
 def setup(request, golden):
     scene = pc.load_scene(request.param)
     return request.param, scene, el.EmulRayTracer().setScene(scene), golden("scene_" + request.param.replace("_opaque", ""))

@@ -22,7 +22,7 @@ def rt0():
     return gi.RayTracer(0)
 
 
-@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque", "textures_opaque"])
+@pytest.fixture(scope="module", params=["test_scene", "cornell", "caustics", "spheres_opaque", "textures_opaque", "caustics_02"])
 def setup(request, golden):
     scene = pc.load_scene(request.param)
     return request.param, scene, gi.RayTracer(0).setScene(scene), golden("scene_" + request.param.replace("_opaque", ""))
@@ -141,7 +141,7 @@ def test_emission_identical_to_oracle(setup):
 def test_render_matches_oracle(setup, adaptive, mode):
     name, scene, rt, fx = setup
     rt.set_render_mode(mode)
-    glassy = name == "textures_opaque"   # a glass sphere among bright textures: see test_textured_scene_matches_oracle
+    glassy = name in ("textures_opaque", "caustics_02")   # glass next to bright surfaces: see test_textured_scene_matches_oracle
     try:
         rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, adaptive, tol=1e-3 if glassy else pc.RMSE_TOL, spp_mismatch=0.05 if glassy else 0.0)
     finally:

@@ -7,7 +7,7 @@ import gi_raytracer_amd as gi
 import parity_checks as pc
 
 
-@pytest.mark.parametrize("name", ["test_scene", "cornell", "caustics", "spheres_opaque"])
+@pytest.mark.parametrize("name", ["test_scene", "cornell", "caustics", "spheres_opaque", "caustics_02"])
 def test_loader_octree_photon_map_identical_to_reference(golden, name):
     fx = golden("scene_" + name.replace("_opaque", ""))
     s = pc.load_scene(name)

@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib as ol
 
-SCENES = ["test_scene", "cornell", "caustics", "spheres", "textures"]
+SCENES = ["test_scene", "cornell", "caustics", "spheres", "textures", "caustics_02"]
 
 
 def P(a):
@@ -145,7 +145,7 @@ def test_textures_get_and_alpha_bit_exact(golden):
 # ------------------------------------------------------------------ whole frames on the pinned RNG chain (a-1, a-2, a-10, f1)
 @pytest.mark.parametrize("name", ["chain_test_scene_lin", "chain_caustics_lin", "chain_cornell_lin", "chain_caustics_run", "chain_cornell_run",
                                   "chain_spheres_lin", "chain_spheres_run", "chain_fog_lin", "chain_fog_run",
-                                  "chain_textures_lin", "chain_textures_run"])
+                                  "chain_textures_lin", "chain_textures_run", "chain_caustics_02_lin", "chain_caustics_02_run"])
 def test_whole_frame_matches_reference_bit_for_bit(golden, name):
     """The reference's frame (its own RayTracer::run for *_run; radiance() per sample for *_lin) on a pinned time() and
     one OpenMP thread, including tracePhotons and the photon-map build, reproduced by the oracle's chain RNG mode."""
