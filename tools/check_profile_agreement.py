@@ -15,6 +15,7 @@ for r in rows:
     key = n.split("(")[0].replace("void ", "")[:32]
     parts[key] = parts.get(key, 0.0) + t
 print("rocprof kernel durations per frame: %.1f ms; bench.py HIP events: %.1f ms (ratio %.4f)" % (tot, d["roofline"]["kernel_ms"], tot / d["roofline"]["kernel_ms"]))
-dom = d["roofline"]["dominant"]
-k = [v for n, v in parts.items() if n.startswith(dom["kernel"])]
-print("dominant %s: rocprof %.1f ms, bench.py %.1f ms" % (dom["kernel"], sum(k), dom["ms_per_frame"]))
+stages = d["roofline"]["stage_ms"]
+name = max(stages, key=stages.get)                        # the dominant stage (trace / shade / gather: one kernel each)
+k = [v for n, v in parts.items() if n.startswith("k_st_" + name)]
+print("dominant k_st_%s: rocprof %.1f ms, bench.py %.1f ms" % (name, sum(k), stages[name]))
