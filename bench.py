@@ -58,8 +58,9 @@ def measured_traffic(scene, w, h, spp, photons, world, mode):
     if best is None:
         return None
     path, d = best
+    per_kernel = {k: 2.0 * v["FETCH_SIZE_KB"] * 1024 + v["WRITE_SIZE_KB"] * 1024 for k, v in d.get("per_kernel", {}).items()}
     return {"traffic": 2.0 * d["frame_fetch_bytes_uncorrected"] + d["frame_write_bytes"], "traffic_unit": "bytes per frame (one pass of the pipeline)",
-            "traffic_source": os.path.relpath(path, ROOT) + ": 2 x FETCH_SIZE + WRITE_SIZE"}
+            "traffic_source": os.path.relpath(path, ROOT) + ": 2 x FETCH_SIZE + WRITE_SIZE", "_per_kernel": per_kernel}
 
 
 def main():
@@ -227,7 +228,11 @@ def main():
                                                "achieved": a, "frac": a / HBM_PEAK_GBS}
         tr = measured_traffic(args.scene, w, h, spp, args.photons, world, args.mode)
         if tr is not None:
+            per_kernel = tr.pop("_per_kernel")
             out["roofline"].update(tr)
+            dom = out["roofline"].get("dominant")
+            if dom and dom["kernel"] in per_kernel:      # the dominant kernel's own HBM bytes per frame (all its launches)
+                dom["traffic"] = per_kernel[dom["kernel"]]
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
