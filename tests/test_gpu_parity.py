@@ -246,7 +246,9 @@ def test_errors_are_reported_not_swallowed():
         gi.RayTracer(99)                      # no such device
 
 
-@pytest.mark.parametrize("name,w,h,spp,photons", [("test_scene", 256, 256, 1, 0), ("cornell", 512, 512, 4, 0), ("caustics", 1920, 1080, 2, 20000)])
+@pytest.mark.parametrize("name,w,h,spp,photons", [("test_scene", 256, 256, 1, 0), ("cornell", 512, 512, 4, 0), ("caustics", 1920, 1080, 2, 20000),
+                                                    # 4K: other Halton enumeration constants (2^12 x 3^7), 8.3 M pixels, 17 stripes of 16 rows per rank
+                                                    ("caustics", 3840, 2160, 1, 20000)])
 def test_full_size_properties(name, w, h, spp, photons):
     """BASELINE frame sizes (configs 1-3) at reduced spp: properties that do not need the oracle."""
     scene = pc.load_scene(name)
