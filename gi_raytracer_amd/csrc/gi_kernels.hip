@@ -942,6 +942,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     }
     c->S.hdims = c->d_hdims.p;
     c->S.htable = c->d_htable.p;
+    if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
     if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."

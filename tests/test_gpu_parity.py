@@ -238,6 +238,20 @@ def test_no_photon_map_gather_is_zero():
     assert (res == 0).all() and nc[0] == 0
 
 
+def test_sample_chunks_give_the_same_frame(monkeypatch):
+    """A frame whose per-sample radiance buffer exceeds the budget (16 GiB by default) is rendered in chunks of samples, each folded
+    into the running mean in order: same bits as in one piece.  Here the budget is shrunk to two samples per chunk."""
+    scene = pc.load_scene("caustics")
+    rt = gi.RayTracer(0).setScene(scene)
+    rt.tracePhotons(3000)
+    a = rt.run(40, 30, min_samples=7, max_samples=7)
+    monkeypatch.setenv("GI_LBUF_MAX_BYTES", str(40 * 30 * 24 * 2))
+    rt2 = gi.RayTracer(0).setScene(scene)          # the budget is read when the context is created
+    rt2.tracePhotons(3000)
+    b = rt2.run(40, 30, min_samples=7, max_samples=7)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 def test_errors_are_reported_not_swallowed():
     rt = gi.RayTracer(0)
     with pytest.raises(gi.GiError):
