@@ -513,6 +513,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gkeys(Scene S, const PathRec* p
 // scans them from there -- a broadcast LDS read per candidate instead of an L2 round trip per lane.  Waves that straddle a leaf
 // boundary take the per-lane walk.  Both run g_key / g_acc / g_end, i.e. the same arithmetic in the same order.
 #define GI_GCHUNK 64
+#define GI_GATHER_WAVES 4      // waves per SIMD the gather kernel is compiled for (launch bound)
 // Pass 1 of the cooperative path keeps a lane's 32 smallest keys sorted in 32 registers and folds the candidates in 32 at a time:
 // sort the 32 new keys (bitonic network), take min(best[i], new[31 - i]) -- the 32 smallest of the 64, as a bitonic sequence --
 // and merge.  21 branch-free instructions per candidate; the LDS heap costs ~55, because with 64 lanes some lane always has to
@@ -540,11 +541,14 @@ __device__ __forceinline__ void kmerge32(float (&v)[32])   // bitonic sequence -
             if (l > i) kce(v[i], v[l]);
         }
 }
-__global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in)
+__global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in)
 {
-    __shared__ float heap[GI_GATHER_K * GI_BLOCK];
-    __shared__ double cand[GI_BLOCK / 64][GI_GCHUNK][9];
+    // 8 KB of LDS per wave: the staged candidates of the cooperative path (64 x 9 doubles) or the float heaps of the per-lane walk (32 x 64),
+    // never both at once -- a wave is in one of the two, and the tie pass runs after the last candidate was read
+    __shared__ __align__(16) float lds[GI_GATHER_K * GI_BLOCK];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float* const heap = lds + wave * (GI_GATHER_K * 64) + lane;                       // element i of this lane's heap at heap[i * 64]
+    double (*const cand)[9] = reinterpret_cast<double (*)[9]>(lds + wave * (GI_GATHER_K * 64));   // cand[k] = staged candidate k of this wave
     const uint32_t n_round = (n_in + 63u) & ~63u;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_round; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = i0 + lane;
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
         const bool has_leaf = valid && leaf < (uint32_t)S.n_pnode;
         const bool uniform = __ballot(valid && leaf != leaf0) == 0ull && leaf0 < (uint32_t)S.n_pnode;
         if (!uniform) {
-            if (has_leaf) stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap + threadIdx.x, GI_BLOCK);
+            if (has_leaf) stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap, 64);
             continue;
         }
         const PNode& lf = S.pnodes[leaf0];
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
         const PRange* ranges = S.pranges + lf.nb_off;
         GatherAcc a;
         PathRec* p = valid ? &pool[vals[i]] : nullptr;
-        g_begin(a, valid ? ld3(p->hpos) : v3(0, 0, 0), valid ? ld3(p->gdir) : v3(0, 0, 0), heap + threadIdx.x, GI_BLOCK, ncand);
+        g_begin(a, valid ? ld3(p->hpos) : v3(0, 0, 0), valid ? ld3(p->gdir) : v3(0, 0, 0), heap, 64, ncand);
         float best[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) best[k] = INFINITY;
@@ -577,10 +581,10 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
                     while (off >= ranges[r].count) { off -= ranges[r].count; r++; }   // r < n_ranges: off < ncand = sum of the counts
                     const size_t ph = (size_t)(ranges[r].first + off);
                     const double* pp = S.ph_pos + ph * 3;
-                    cand[wave][lane][0] = pp[0]; cand[wave][lane][1] = pp[1]; cand[wave][lane][2] = pp[2];
+                    cand[lane][0] = pp[0]; cand[lane][1] = pp[1]; cand[lane][2] = pp[2];
                     if (pass == 1) {
                         const double* dc = S.ph_dircol + ph * 6;
-                        for (int k = 0; k < 6; k++) cand[wave][lane][3 + k] = dc[k];
+                        for (int k = 0; k < 6; k++) cand[lane][3 + k] = dc[k];
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
 #pragma unroll
                         for (int k = 0; k < 32; k++) {
                             const int kk = k0 + k < m ? k0 + k : m - 1;                 // wave-uniform clamp: no out-of-range LDS read
-                            const double* q = cand[wave][kk];
+                            const double* q = cand[kk];
                             const float key = (float)len2(v3(q[0], q[1], q[2]) - a.pos);   // same expression as g_key
                             nk[k] = k0 + k < m ? key : INFINITY;
                         }
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
                     }
                 } else if (valid) {
                     for (int32_t k = 0; k < m; k++) {
-                        const double* q = cand[wave][k];
+                        const double* q = cand[k];
                         g_acc(a, v3(q[0], q[1], q[2]), q + 3);
                     }
                 }
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_st_gather(Scene S, PathRec* pool, 
         }
         if (valid) {
             V3 caustic;
-            if (!g_end(a, caustic)) caustic = gather_in_leaf(S, (int32_t)leaf0, a.pos, a.dir, heap + threadIdx.x, GI_BLOCK, nullptr, nullptr);   // float-key tie: exact pass
+            if (!g_end(a, caustic)) caustic = gather_in_leaf(S, (int32_t)leaf0, a.pos, a.dir, heap, 64, nullptr, nullptr);   // float-key tie: exact pass
             V3 L = ld3(p->L) + ld3(p->gcoef) * caustic;
             p->L[0] = L.x; p->L[1] = L.y; p->L[2] = L.z;
         }
