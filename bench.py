@@ -46,7 +46,9 @@ def measured_traffic(scene, w, h, spp, photons, world, mode):
     MI355X_MICROARCH.md (HBM section) prescribes for gfx950."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+    import re
+    natural = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]   # r01_v10 after r01_v9
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=natural):
         try:
             with open(path) as f:
                 d = json.load(f)
