@@ -17,5 +17,4 @@ for world in [int(a) for a in sys.argv[1:]] or (1, 2, 4, 8):
         torch.cuda.synchronize()
     ms = rt.last_render_ms()[0]
     st = rt.last_stage_ms()
-    base = 974.0
     print(world, rows, round(ms, 1), "eff", round(base / (ms * world), 3), {k: round(v, 1) for k, v in st.items()}, flush=True)
