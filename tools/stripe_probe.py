@@ -7,6 +7,7 @@ scene = gi.Scene.load("scenes/caustics/caustics.scn").rebuild()
 rt = gi.RayTracer(0).setScene(scene)
 rt.tracePhotons(200000)
 w, h, spp = 1920, 1080, 256
+base = None          # time of the whole frame, when world 1 is among the runs
 for world in [int(a) for a in sys.argv[1:]] or (1, 2, 4, 8):
     sh = 16 if world > 1 else h
     p = rt.params(w, h, stripe_h=sh, rank=0, world=world, min_samples=spp, max_samples=spp)
@@ -17,4 +18,6 @@ for world in [int(a) for a in sys.argv[1:]] or (1, 2, 4, 8):
         torch.cuda.synchronize()
     ms = rt.last_render_ms()[0]
     st = rt.last_stage_ms()
-    print(world, rows, round(ms, 1), "eff", round(base / (ms * world), 3), {k: round(v, 1) for k, v in st.items()}, flush=True)
+    if world == 1:
+        base = ms
+    print(world, rows, round(ms, 1), "speed-up", round(base / ms, 2) if base else None, {k: round(v, 1) for k, v in st.items()}, flush=True)
