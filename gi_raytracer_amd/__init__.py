@@ -58,11 +58,11 @@ _LIB = None
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
     "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
-    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index",
+    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_texture", "gih_add_material_tex", "gih_load_png", "gih_free",
     "gih_add_light", "gih_add_sphere", "gih_add_height_fog", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
-    "gih_counts", "gih_build_photon_map", "gih_get_photon_desc",
+    "gih_counts", "gih_build_photon_map", "gih_get_photon_desc", "gih_to_rgb8",
 ]
 
 
@@ -99,6 +99,8 @@ def lib():
     L.gi_emit_photons.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint64, _dp, C.c_int32, C.POINTER(C.c_int64)]
     L.gi_halton_sample.argtypes = [vp, C.c_int32, _up, _up, C.POINTER(C.c_float)]
     L.gi_halton_index.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _up, _up]
+    L.gi_debug_leaf_order.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _ip]
+    L.gi_kat.argtypes = [vp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp]
     L.gih_scene_create.restype = vp
     L.gih_scene_destroy.argtypes = [vp]
     L.gih_last_error.argtypes = [vp]
@@ -121,6 +123,7 @@ def lib():
     L.gih_counts.argtypes = [vp, _ip, _ip, _ip, _ip, _ip]
     L.gih_build_photon_map.argtypes = [vp, C.c_int32, _dp]
     L.gih_get_photon_desc.argtypes = [vp, C.POINTER(PhotonMapDesc)]
+    L.gih_to_rgb8.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_uint8)]
     _LIB = L
     return L
 
@@ -303,8 +306,12 @@ def save_pfm(path, lin):
 
 def to_rgb8(lin):
     """The reference's display transform: gamma 2.2, clamp to [0, 1], truncating (int)(255 c) (include/raytracer.h:150-157, image.h:15)."""
-    c = np.clip(np.power(np.maximum(np.asarray(lin, np.float64), 0.0), 1.0 / 2.2), 0.0, 1.0)
-    return (255 * c).astype(np.int32).astype(np.uint8)
+    a = np.asarray(lin)
+    a = np.ascontiguousarray(a, np.float32 if a.dtype == np.float32 else np.float64)
+    out = np.zeros(a.shape, np.uint8)
+    if lib().gih_to_rgb8(a.ctypes.data_as(C.c_void_p), 1 if a.dtype == np.float64 else 0, a.size, out.ctypes.data_as(C.POINTER(C.c_uint8))) != 0:
+        raise GiError("to_rgb8: invalid arguments")
+    return out
 
 
 def save_ppm(path, lin):
@@ -466,6 +473,25 @@ class RayTracer:
         out = np.zeros((len(rays), 3))
         self._check(self.L.gi_radiance(self.h, len(rays), _p(rays), _p(stream, _up), C.c_uint64(self.seed if seed is None else seed), _p(out)), "radiance")
         return out
+
+    KAT = {"fastPow": 0, "fastPrecisePow": 1, "hemisphereSample_cos": 2, "sample_phong": 3, "sphereCapSample_cos": 4, "randomUnitVec": 5, "refr": 6, "reflect": 7,
+           "sin": 16, "cos": 17, "acos": 18, "asin": 19, "atan2": 20, "pow": 21, "sqrt": 22}
+
+    def kat(self, what, args):
+        """Known answers of the scalar building blocks as the device computes them (include/gi_hip.h: gi_kat); args [n][k] -> [n][3]."""
+        a = _f64(args)
+        a = a.reshape(len(a), -1)
+        out = np.zeros((len(a), 3))
+        self._check(self.L.gi_kat(self.h, self.KAT[what], len(a), _p(a), a.shape[1], _p(out)), "kat")
+        return out
+
+    def leaf_order(self, rays, cap=256):
+        """Octree::intersectSorted as the device walk produces it: per ray the pre-order indices of the non-empty leaves in visiting order."""
+        rays = _f64(rays).reshape(-1, 6)
+        leaf = np.zeros((len(rays), cap), np.int32); n = np.zeros(len(rays), np.int32)
+        self._check(self.L.gi_debug_leaf_order(self.h, len(rays), _p(rays), cap, _p(leaf, _ip), _p(n, _ip)), "leaf_order")
+        assert (n <= cap).all(), "leaf_order: cap too small"
+        return [leaf[i, :n[i]].copy() for i in range(len(rays))]
 
     def halton_sample(self, dim, index):
         dim = np.ascontiguousarray(dim, np.uint32); index = np.ascontiguousarray(index, np.uint32)

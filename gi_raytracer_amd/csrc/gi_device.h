@@ -1009,6 +1009,70 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
     return S.n_tex > 0 ? visible_nodes<7>(S, N, ray, mt, rng, light_index, c) : visible_nodes<3>(S, N, ray, mt, rng, light_index, c);
 }
 
+// ------------------------------------------------------------------------------------------------ diagnostics (parity tests)
+// The sequence of non-empty leaves the walk of trace() meets for a ray, as canonical (pre-order) node indices, without the early
+// stop of trace: what Octree::intersectSorted (include/octree.cpp:188-211,285-313) returns as its t0-sorted list.  Runs the very
+// walk the kernels run (wide records when the scene has them, else the per-node links).
+GI_HD int leaf_order(const Scene& S, const Ray& ray, int cap, int32_t* out)
+{
+    int n = 0;
+    if (S.wnodes) {
+        GlobalWide W;
+        W.g = S.wnodes;
+        const WRay wr = wray_make(ray);
+        WWalk k;
+        if (!wwalk_begin(S, W, k, ray, wr, 0.0, INFINITY)) return 0;
+        for (;;) {
+            int32_t lnode = 0, first = 0, cnt = 0;
+            int lslot = 0;
+            if (!wwalk_next_leaf(W, k, ray, wr, 0.0, INFINITY, lnode, lslot, first, cnt)) break;
+            if (n < cap) out[n] = S.wleaf_id[lnode * 8 + lslot];
+            n++;
+        }
+        return n;
+    }
+    GlobalNodes N;
+    N.g = S.tnodes;
+    const int oct = dir_octant(ray);
+    int32_t node = 0;
+    while (node < S.n_node) {
+        NodeView nd;
+        N.fetch(node, oct, nd);
+        if (!box_hit(nd.bmin, nd.bmax, ray, 0.0, INFINITY)) { node = nd.skip; continue; }
+        if (nd.n_ref < 0) { node = nd.hit; continue; }
+        if (nd.n_ref > 0) { if (n < cap) out[n] = N.leaf_id(node); n++; }
+        node = nd.skip;
+    }
+    return n;
+}
+// Known-answer access to the scalar building blocks (include/util.h:100-188, include/util.cpp:27-107) and to the libm calls the path
+// makes, as the device evaluates them.  in: up to 9 doubles, out: 3 doubles.
+enum { KAT_FAST_POW = 0, KAT_FAST_PRECISE_POW = 1, KAT_HEMI_COS_N = 2, KAT_SAMPLE_PHONG = 3, KAT_SPHERE_CAP = 4, KAT_UNIT_VEC = 5, KAT_REFR = 6, KAT_REFLECT = 7,
+       KAT_SIN = 16, KAT_COS = 17, KAT_ACOS = 18, KAT_ASIN = 19, KAT_ATAN2 = 20, KAT_POW = 21, KAT_SQRT = 22 };
+GI_HD void kat_eval(int what, const double* in, double* out)
+{
+    V3 r = v3(0, 0, 0);
+    switch (what) {
+    case KAT_FAST_POW: r.x = fast_pow(in[0], in[1]); break;
+    case KAT_FAST_PRECISE_POW: r.x = fast_precise_pow(in[0], in[1]); break;
+    case KAT_HEMI_COS_N: r = hemi_cos_n(ld3(in), (float)in[3], (float)in[4], in[5]); break;
+    case KAT_SAMPLE_PHONG: r = sample_phong(ld3(in), in[3], in[4], in[5]); break;
+    case KAT_SPHERE_CAP: r = sphere_cap_cos(ld3(in), (float)in[3], (float)in[4], in[5], in[6]); break;
+    case KAT_UNIT_VEC: r = random_unit_vec(in[0], in[1]); break;
+    case KAT_REFR: r = refr(ld3(in), ld3(in + 3), in[6]); break;
+    case KAT_REFLECT: r = reflect(ld3(in), ld3(in + 3)); break;
+    case KAT_SIN: r.x = sin(in[0]); break;
+    case KAT_COS: r.x = cos(in[0]); break;
+    case KAT_ACOS: r.x = acos(in[0]); break;
+    case KAT_ASIN: r.x = asin(in[0]); break;
+    case KAT_ATAN2: r.x = atan2(in[0], in[1]); break;
+    case KAT_POW: r.x = pow(in[0], in[1]); break;
+    case KAT_SQRT: r.x = sqrt(in[0]); break;
+    default: break;
+    }
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
 // ------------------------------------------------------------------------------------------------ photon gather
 // Lane-private max-heap of GI_GATHER_K *float* keys; element i of this lane lives at hp[i * stride] (LDS, bank-conflict free
 // for any per-lane i because the lane index is the fastest-varying address component).  Keys are (float)d2: rounding is

@@ -6,6 +6,7 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -838,6 +839,19 @@ int gih_get_photon_desc(const gih_scene* s, gi_photon_map_desc* d)
     d->photons = s->photons.data();
     d->n_node = (int32_t)(s->pm_bbox.size() / 6);
     d->node_bbox = s->pm_bbox.data(); d->node_child = s->pm_child.data(); d->node_off = s->pm_off.data(); d->node_idx = s->pm_idx.data();
+    return 0;
+}
+
+// gamma(color, 2.2), glm::clamp(color, 0, 1), Image::setPixel's (int)(255 c) (include/raytracer.h:150-157, include/util.h:94-97, include/image.h:14-16).
+// pow of a negative channel is NaN, which the reference's clamp lets through and its cast turns into 0 (known answers: tests/golden/kat.npz kat_pixel).
+int gih_to_rgb8(const void* lin, int32_t is_f64, int64_t n_values, uint8_t* out)
+{
+    if (n_values < 0 || (n_values && (!lin || !out))) return -1;
+    for (int64_t i = 0; i < n_values; i++) {
+        const double c = is_f64 ? static_cast<const double*>(lin)[i] : (double)static_cast<const float*>(lin)[i];
+        const double g = std::pow(c, 1.0 / 2.2);
+        out[i] = g != g ? (uint8_t)0 : (uint8_t)(int)(255 * std::min(std::max(g, 0.0), 1.0));
+    }
     return 0;
 }
 

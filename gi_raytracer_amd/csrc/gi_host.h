@@ -67,6 +67,11 @@ int gih_counts(const gih_scene*, int32_t* n_tri, int32_t* n_mat, int32_t* n_ligh
 int gih_build_photon_map(gih_scene*, int32_t n, const double* photons);
 int gih_get_photon_desc(const gih_scene*, gi_photon_map_desc* out);
 
+/* replaces the 8-bit sink of RayTracer::run (include/raytracer.h:150-157: gamma(color, 2.2), glm::clamp) + Image::setPixel
+ * (include/image.h:14-16: truncating (int)(255 c)): n_values linear channel values (float or double) -> bytes.  A negative value
+ * (the caustic term can be negative) gives 0, as in the reference.                                                      */
+int gih_to_rgb8(const void* lin, int32_t is_f64, int64_t n_values, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

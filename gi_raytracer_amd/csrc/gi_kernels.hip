@@ -798,6 +798,23 @@ __global__ __launch_bounds__(GI_BLOCK) void k_emit(Scene S, int count, int max_d
     if (ok) out[j] = po;
 }
 
+__global__ __launch_bounds__(GI_BLOCK) void k_leaf_order(Scene S, int n, const double* rays, int cap, int32_t* leaf_out, int32_t* n_out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rays + (size_t)i * 6;
+    n_out[i] = leaf_order(S, make_ray_exact(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])), cap, leaf_out + (size_t)i * cap);
+}
+__global__ __launch_bounds__(GI_BLOCK) void k_kat(int what, int n, const double* in, int in_stride, double* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a[9], o[3];
+    for (int k = 0; k < 9; k++) a[k] = k < in_stride ? in[(size_t)i * in_stride + k] : 0.0;
+    kat_eval(what, a, o);
+    for (int k = 0; k < 3; k++) out[(size_t)i * 3 + k] = o[k];
+}
+
 __global__ void k_halton(Scene S, int n, const uint32_t* dim, const uint32_t* index, float* out)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1599,6 +1616,40 @@ int gi_emit_photons(gi_ctx* c, int32_t count, int32_t max_depth, uint64_t seed, 
     if (tries_out) *tries_out = tries;
     if (stored > cap) return fail(c, GI_E_INVALID, "emit_photons: output capacity too small");
     return stored;
+}
+
+int gi_debug_leaf_order(gi_ctx* c, int32_t n, const double* rays, int32_t cap, int32_t* leaf_out, int32_t* n_out)
+{
+    if (!c || n < 0 || cap < 1 || (n && (!rays || !leaf_out || !n_out))) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "leaf_order: no scene uploaded");
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_r;
+    DevBuf<int32_t> d_l, d_n;
+    HIP_TRY(c, d_r.upload(std::vector<double>(rays, rays + (size_t)n * 6)));
+    HIP_TRY(c, d_l.alloc((size_t)n * cap)); HIP_TRY(c, d_n.alloc(n));
+    HIP_TRY(c, hipMemsetAsync(d_l.p, 0xff, (size_t)n * cap * 4, c->stream));
+    hipLaunchKernelGGL(k_leaf_order, GI_GRID(n), 0, c->stream, c->S, n, d_r.p, cap, d_l.p, d_n.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(leaf_out, d_l.p, (size_t)n * cap * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(n_out, d_n.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_kat(gi_ctx* c, int32_t what, int32_t n, const double* in, int32_t in_stride, double* out3)
+{
+    if (!c || n < 0 || in_stride < 1 || in_stride > 9 || (n && (!in || !out3))) return GI_E_INVALID;
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_i, d_o;
+    HIP_TRY(c, d_i.upload(std::vector<double>(in, in + (size_t)n * in_stride)));
+    HIP_TRY(c, d_o.alloc((size_t)n * 3));
+    hipLaunchKernelGGL(k_kat, GI_GRID(n), 0, c->stream, what, n, d_i.p, in_stride, d_o.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out3, d_o.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return GI_OK;
 }
 
 int gi_halton_sample(gi_ctx* c, int32_t n, const uint32_t* dim, const uint32_t* index, float* out)

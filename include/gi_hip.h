@@ -157,6 +157,18 @@ int gi_emit_photons(gi_ctx*, int32_t count, int32_t max_depth, uint64_t seed, do
 int gi_halton_sample(gi_ctx*, int32_t n, const uint32_t* dim, const uint32_t* index, float* out);
 int gi_halton_index(gi_ctx*, int32_t width, int32_t height, int32_t n, const uint32_t* sxy /*[n][3]*/, uint32_t* out);
 
+/* Diagnostics for parity tests (not needed to render).
+ * gi_debug_leaf_order: what Octree::intersectSorted(ray, 0, inf) returns (include/octree.cpp:188-211,285-313) as the device walk produces
+ * it: for ray i, the non-empty leaves in visiting order as pre-order node indices in leaf_out[i*cap ..], their number in n_out[i]
+ * (may exceed cap; only cap are stored).  Uses the walk the kernels use (wide records or per-node links, gi_set_wide_nodes).
+ * gi_kat: known answers of the scalar building blocks as the device computes them.  what: 0 fastPow(a,b), 1 fastPrecisePow(a,b)
+ * (include/util.h:100-136), 2 hemisphereSample_cos(n,u,v,power), 3 sample_phong(outdir,power,sx,sy), 4 sphereCapSample_cos(n,u,v,power,frac)
+ * (include/util.cpp:35-107), 5 randomUnitVec(x,y), 6 refr(inc,n,eta) (include/util.h:173-188), 7 glm::reflect(inc,n); 16..22 the libm
+ * calls of the path: sin, cos, acos, asin, atan2(a,b), pow(a,b), sqrt.  in [n][in_stride] (arguments in the order given), out3 [n][3].  */
+int gi_debug_leaf_order(gi_ctx*, int32_t n, const double* rays, int32_t cap, int32_t* leaf_out, int32_t* n_out);
+int gi_kat(gi_ctx*, int32_t what, int32_t n, const double* in, int32_t in_stride, double* out3);
+
+
 #ifdef __cplusplus
 }
 #endif

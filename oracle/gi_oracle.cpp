@@ -1328,6 +1328,16 @@ int gio_trace(gio_ctx* c, int n, const double* rays, int32_t* hit, int32_t* ent,
     return 0;
 }
 
+// gamma (util.h:94-97), glm::clamp, Image::setPixel (image.h:14-16) for one channel.  pow of a negative value is NaN; the reference's clamp
+// passes it on and its (int) cast yields INT_MIN on x86, i.e. byte 0 (pinned by kat_pixel, captured from the reference's own Image).
+static uint8_t pixel8(double lin)
+{
+    const double g = std::pow(lin, 1.0 / 2.2);
+    if (g != g) return 0;
+    return (uint8_t)(int)(255 * std::min(std::max(g, 0.0), 1.0));
+}
+void gio_pixel8(int n, const double* lin, uint8_t* out) { for (int i = 0; i < n; i++) out[i] = pixel8(lin[i]); }
+
 int gio_leaf_order(gio_ctx* c, const double* ray6, int cap, int32_t* node, double* t0)
 {
     if (!c->octree_valid) return -1;
@@ -1463,11 +1473,8 @@ static int render_rows(gio_ctx* c, int w, int h, int n_rows, const int32_t* rows
                 if (out_spp) out_spp[(size_t)y * w + x] = taken;
                 if (out_u8) {
                     // gamma (util.h:94-97), glm::clamp, Image::setPixel (image.h:14-16)
-                    double g[3] = {std::pow(lin.x, 1.0 / 2.2), std::pow(lin.y, 1.0 / 2.2), std::pow(lin.z, 1.0 / 2.2)};
-                    for (int k = 0; k < 3; k++) {
-                        double v = std::min(std::max(g[k], 0.0), 1.0);
-                        out_u8[o + k] = (uint8_t)(int)(255 * v);
-                    }
+                    const double l3[3] = {lin.x, lin.y, lin.z};
+                    for (int k = 0; k < 3; k++) out_u8[o + k] = pixel8(l3[k]);
                 }
             }
         }

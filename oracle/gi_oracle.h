@@ -58,6 +58,8 @@ int gio_ent_bbox(gio_ctx*, double* bbox /* [n_ent][6] */);
 int gio_trace(gio_ctx*, int n, const double* rays, int32_t* hit, int32_t* ent, double* res, int32_t* n_leaves);
 /* sorted leaf list of one ray: returns count, fills up to cap entries (node pre-order index, t0) */
 int gio_leaf_order(gio_ctx*, const double* ray6, int cap, int32_t* node, double* t0);
+/* the 8-bit sink of RayTracer::run for n channel values: gamma 2.2, clamp, (int)(255 c) (raytracer.h:150-157, image.h:14-16) */
+void gio_pixel8(int n, const double* lin, uint8_t* out);
 /* RayTracer::visible (include/raytracer.h:280-319): q [n][6] = origin, target point; mt = |target-origin|^2 */
 int gio_visible(gio_ctx*, int n, const double* q, int32_t* vis, int32_t* n_cand);
 

@@ -103,6 +103,8 @@ static int cmd_halton(const std::string& out)
             unsigned smax = e.get_max_samples_per_pixel();
             unsigned s = (t < 4) ? (unsigned)t : (unsigned)(lcg.next() * std::min(smax, 1024u));
             if (t == 5) s = smax - 1;
+            if (t == 6) s = smax;            // past the last sample a pixel can address: the 32-bit index wraps (include/halton_enum.h:109-113)
+            if (t == 7) s = smax + 544;      // 4K: sample 1023 of BASELINE config 5
             gi.insert(gi.end(), {k, s, x, y, e.get_index(s, x, y)});
         }
         for (int t = 0; t < 8; t++) {
@@ -211,6 +213,30 @@ static int cmd_kat(const std::string& out)
         tb.insert(tb.end(), {c.x, c.y, c.z, hsz.x, hsz.y, hsz.z, tv[0].x, tv[0].y, tv[0].z, tv[1].x, tv[1].y, tv[1].z, tv[2].x, tv[2].y, tv[2].z, r ? 1.0 : 0.0});
     }
     save_f64(out + "/kat_tribox.npy", tb, {tb.size() / 16, 16});
+
+    // the 8-bit sink (include/raytracer.h:150-157, include/image.h:14-16): gamma(color, 2.2), glm::clamp(color, 0, 1), Image::setPixel, read back.
+    // Rows: linear colour (3) | the bytes QImage holds afterwards (3).  Includes negative channels (pow of a negative base is NaN, which
+    // survives glm::clamp and makes the QColor invalid), values above 1, exact 0 and 1, and values around the k/255 thresholds.
+    {
+        std::vector<double> px;
+        std::vector<glm::dvec3> in;
+        in.push_back(glm::dvec3(0, 0, 0)); in.push_back(glm::dvec3(1, 1, 1)); in.push_back(glm::dvec3(0.5, 0.5, 0.5));
+        in.push_back(glm::dvec3(-0.25, 0.3, 0.6)); in.push_back(glm::dvec3(0.3, -1e-9, 0.6)); in.push_back(glm::dvec3(0.3, 0.6, -3.0));
+        in.push_back(glm::dvec3(-0.1, -0.2, -0.3)); in.push_back(glm::dvec3(2.5, 0.2, 1.0000001)); in.push_back(glm::dvec3(1e-12, 1e-300, 0.999999999));
+        in.push_back(glm::dvec3(-0.0, 0.25, 0.75));
+        for (int k = 1; k < 256; k += 7) { const double t = std::pow(k / 255.0, 2.2); in.push_back(glm::dvec3(t, std::nextafter(t, 0.0), std::nextafter(t, 1.0))); }
+        for (int t = 0; t < 160; t++) in.push_back(glm::dvec3(lcg.next() * 1.2 - 0.1, lcg.next() * lcg.next(), lcg.next() * 3 - 0.5));
+        Image img((int)in.size(), 1);
+        for (size_t i = 0; i < in.size(); i++) {
+            glm::dvec3 color = gamma(in[i], 2.2);
+            img.setPixel((int)i, 0, glm::clamp(color, 0.0, 1.0));
+        }
+        for (size_t i = 0; i < in.size(); i++) {
+            const glm::dvec3 q = img.getPixel((int)i, 0);
+            px.insert(px.end(), {in[i].x, in[i].y, in[i].z, std::round(q.x * 255.), std::round(q.y * 255.), std::round(q.z * 255.)});
+        }
+        save_f64(out + "/kat_pixel.npy", px, {px.size() / 6, 6});
+    }
 
     // xorshift64* stream from the pinned seed (include/util.h:52-80): first 64 drand() values of this thread
     std::vector<double> dr;

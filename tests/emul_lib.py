@@ -39,6 +39,8 @@ def lib():
         L.emul_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.emul_rng.restype = C.c_double
         L.emul_set_wide.argtypes = [vp, C.c_int]
+        L.emul_leaf_order.argtypes = [vp, C.c_int, _dp, C.c_int, _ip, _ip]
+        L.emul_kat.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp]
         _LIB = L
     return _LIB
 
@@ -135,6 +137,20 @@ class EmulRayTracer(gi.RayTracer):
         rays = gi._f64(rays).reshape(-1, 6); stream = np.ascontiguousarray(stream, np.uint32); out = np.zeros((len(rays), 3))
         self.E.emul_radiance(self.h, len(rays), gi._p(rays), gi._p(stream, _up), C.c_uint64(self.seed if seed is None else seed), gi._p(out))
         return out
+
+    def kat(self, what, args):
+        a = gi._f64(args)
+        a = a.reshape(len(a), -1)
+        out = np.zeros((len(a), 3))
+        self.E.emul_kat(self.KAT[what], len(a), gi._p(a), a.shape[1], gi._p(out))
+        return out
+
+    def leaf_order(self, rays, cap=256):
+        rays = gi._f64(rays).reshape(-1, 6)
+        leaf = np.zeros((len(rays), cap), np.int32); n = np.zeros(len(rays), np.int32)
+        self.E.emul_leaf_order(self.h, len(rays), gi._p(rays), cap, gi._p(leaf, _ip), gi._p(n, _ip))
+        assert (n <= cap).all()
+        return [leaf[i, :n[i]].copy() for i in range(len(rays))]
 
     def halton_sample(self, dim, index):
         return np.array([self.E.emul_halton_sample(self.h, int(d), int(i)) for d, i in zip(dim, index)], np.float32)

@@ -179,6 +179,23 @@ int emul_emit(Emul* e, int count, int max_depth, uint64_t seed, double* out, int
     if (tries_out) *tries_out = tries;
     return stored;
 }
+int emul_leaf_order(Emul* e, int n, const double* rays, int cap, int32_t* leaf_out, int32_t* n_out)
+{
+    for (int i = 0; i < n; i++) {
+        const double* r = rays + (size_t)i * 6;
+        n_out[i] = leaf_order(e->S, make_ray_exact(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5])), cap, leaf_out + (size_t)i * cap);
+    }
+    return 0;
+}
+int emul_kat(int what, int n, const double* in, int in_stride, double* out3)
+{
+    for (int i = 0; i < n; i++) {
+        double a[9];
+        for (int k = 0; k < 9; k++) a[k] = k < in_stride ? in[(size_t)i * in_stride + k] : 0.0;
+        kat_eval(what, a, out3 + (size_t)i * 3);
+    }
+    return 0;
+}
 float emul_halton_sample(Emul* e, uint32_t dim, uint32_t index) { return halton_sample(e->S, dim, index); }
 uint32_t emul_halton_index(int w, int h, uint32_t s, uint32_t x, uint32_t y) { return halton_index(make_halton_enum(w, h), s, x, y); }
 double emul_rng(uint64_t seed, uint32_t stream, uint32_t depth, uint32_t purpose, uint32_t a, uint32_t b)

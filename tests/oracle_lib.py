@@ -74,6 +74,7 @@ def lib():
         L.gio_trace.argtypes = [C.c_void_p, C.c_int, c_dp, c_ip, c_ip, c_dp, c_ip]
         L.gio_leaf_order.argtypes = [C.c_void_p, c_dp, C.c_int, c_ip, c_dp]
         L.gio_visible.argtypes = [C.c_void_p, C.c_int, c_dp, c_ip, c_ip]
+        L.gio_pixel8.argtypes = [C.c_int, c_dp, C.POINTER(C.c_uint8)]
         L.gio_set_photons.argtypes = [C.c_void_p, C.c_int, c_dp]
         L.gio_photon_count.argtypes = [C.c_void_p]
         L.gio_get_photons.argtypes = [C.c_void_p, c_dp]

@@ -43,6 +43,66 @@ def check_halton(rt, golden):
         assert np.array_equal(got, rows[:, 4])
 
 
+def check_kats(rt, golden):
+    """a-11: the samplers, fastPow / fastPrecisePow, refr, reflect as the device computes them, against the reference's known answers
+    (tests/golden/kat.npz, captured from include/util.h / util.cpp).  fastPow / fastPrecisePow are integer bit manipulation + exact
+    products: bit-exact.  The samplers go through sin / cos / acos / sqrt: bit-exact on the CPU build (glibc, like the reference); on the
+    GPU the libm is OCML, whose results may differ from glibc's in the last bit, so the bound there is 4 ulp of the result's magnitude
+    scale (1.0: these are unit vectors), with the share of bit-exact answers reported."""
+    k = golden("kat")
+    exact = getattr(rt, "libm_is_glibc", False)
+
+    def close(got, ref, what):
+        if exact:
+            assert got.tobytes() == np.ascontiguousarray(ref).tobytes(), what
+        else:
+            assert np.abs(got - ref).max() <= 4 * 2.0 ** -52, (what, np.abs(got - ref).max())
+    pw = k["kat_pow"]
+    assert rt.kat("fastPow", pw[:, :2])[:, 0].tobytes() == np.ascontiguousarray(pw[:, 2]).tobytes()
+    assert rt.kat("fastPrecisePow", pw[:, :2])[:, 0].tobytes() == np.ascontiguousarray(pw[:, 3]).tobytes()
+    h = k["kat_hemi"]
+    close(rt.kat("hemisphereSample_cos", h[:, :6]), h[:, 6:9], "hemisphereSample_cos")
+    ph = k["kat_phong"]
+    close(rt.kat("sample_phong", np.concatenate([ph[:, 0:3], ph[:, 6:9]], 1)), ph[:, 9:12], "sample_phong")
+    c = k["kat_cap"]
+    close(rt.kat("sphereCapSample_cos", c[:, :7]), c[:, 7:10], "sphereCapSample_cos")
+    u = k["kat_unitvec"]
+    close(rt.kat("randomUnitVec", u[:, :2]), u[:, 2:5], "randomUnitVec")
+    r = k["kat_refr"]
+    assert rt.kat("refr", r[:, :7]).tobytes() == np.ascontiguousarray(r[:, 7:10]).tobytes()        # +, *, sqrt only: IEEE-exact everywhere
+    assert rt.kat("reflect", r[:, :6]).tobytes() == np.ascontiguousarray(r[:, 10:13]).tobytes()
+
+
+def check_leaf_order(rt, fx, set_wide=None):
+    """a-4: the leaves the device walk meets for a ray, in order, against Octree::intersectSorted's t0-sorted list of the reference
+    (leaforder_* of the scene fixtures).  The reference orders leaves with equal t0 by insertion (pre-order DFS, include/octree.cpp:285-313);
+    the device's front-to-back order may permute such a group, never anything else -- and the test says how many rays had such a group."""
+    rays = fx["rays"][fx["leaforder_ray"]]
+    off, node, t0 = fx["leaforder_off"], fx["leaforder_node"], fx["leaforder_t0"]
+    out = {}
+    for wide in ((True, False) if set_wide is not None else (None,)):
+        if wide is not None and set_wide(wide) != wide:
+            continue                                     # a tree the wide records do not cover walks per node either way
+        got = rt.leaf_order(rays)
+        n_exact = n_tie = 0
+        for j, g in enumerate(got):
+            ref, rt0 = node[off[j]:off[j + 1]], t0[off[j]:off[j + 1]]
+            assert len(g) == len(ref), (j, g, ref)
+            if np.array_equal(g, ref):
+                n_exact += 1
+                continue
+            # same leaves; every leaf stays inside its group of equal t0
+            assert sorted(g) == sorted(ref), (j, g, ref)
+            pos = {int(v): i for i, v in enumerate(ref)}
+            assert all(rt0[pos[int(v)]] == rt0[i] for i, v in enumerate(g)), (j, g, ref, rt0)
+            n_tie += 1
+        out[wide] = (n_exact, n_tie)
+        assert n_exact > 0.9 * len(got), out
+    if set_wide is not None:
+        set_wide(True)
+    return out
+
+
 def check_trace_table(rt, fx):
     """RayTracer::trace against the reference's own answers: hit flag / entity index exact, hit point and normal bit-exact."""
     hit, ent, res = rt.trace(fx["rays"])

@@ -31,6 +31,16 @@ def test_trace_matches_reference_table(setup):
     pc.check_trace_table(setup[2], setup[3])
 
 
+def test_leaf_sequence_matches_reference_sorted_lists(setup):
+    print(pc.check_leaf_order(setup[2], setup[3], setup[2].set_wide_nodes))
+
+
+def test_sampler_known_answers(golden):
+    rt = el.EmulRayTracer()
+    rt.libm_is_glibc = True          # this build calls the same glibc the reference was run with: bit-exact
+    pc.check_kats(rt, golden)
+
+
 def test_visible_matches_reference_table(setup):
     pc.check_visible_table(setup[2], setup[3])
 

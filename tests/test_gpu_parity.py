@@ -36,6 +36,17 @@ def test_trace_matches_reference_table(setup):
     pc.check_trace_table(setup[2], setup[3])
 
 
+def test_leaf_sequence_matches_reference_sorted_lists(setup):
+    """SURVEY 8 a-4: Octree::intersectSorted's list (include/octree.cpp:285-313) against the leaves the device walk visits, wide and per-node."""
+    res = pc.check_leaf_order(setup[2], setup[3], setup[2].set_wide_nodes)
+    print(setup[0], res)
+
+
+def test_sampler_known_answers(rt0, golden):
+    """device samplers / fastPow / refr against tests/golden/kat.npz (include/util.cpp:27-107, util.h:100-188)."""
+    pc.check_kats(rt0, golden)
+
+
 def test_visible_matches_reference_table(setup):
     pc.check_visible_table(setup[2], setup[3])
 
@@ -44,31 +55,38 @@ def test_wide_walk_equals_per_node_walk(setup):
     pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
 
 
+# Refractive / textured scenes.  The CPU build of the same device code matches the oracle to 1e-17 on all of them (test_device_logic_cpu.py); on
+# the GPU the libm is OCML, which differs from glibc in the last bit of some sin / cos / acos / asin / atan2 / pow results (shares measured by
+# tools/libm_probe.py, DESIGN.md "Numerics").  A specular chain through a refracting object amplifies such a bit until, for a few paths per
+# ten thousand, a later hit / miss or total-internal-reflection decision falls the other way.  Bounds asserted below are the north_star
+# contract (frame RMSE < 1e-4 on linear radiance) or tighter; the measured values (tools/measure_tolerances.py, MI355X) are in the comments.
 @pytest.mark.parametrize("mode", ["wavefront", "rounds", "megakernel"])
 def test_textured_scene_matches_oracle(mode):
     """scenes/textures/tex.scn (the scene the reference fixtures pin the oracle on): checkerboard and PNG textures as diffuse and emissive
-    colour on meshes and spheres, an alpha channel and a 0.7 opacity in the stochastic alpha tests (include/material.h:32-93).
-    The CPU build of the same device code matches the oracle to 1e-17 on this scene (test_device_logic_cpu.py).  On the GPU the libm differs
-    from glibc by <= 1 ulp (asin / atan2 of the sphere coordinates, sin / cos / pow of the lobes), and specular chains through the glass
-    sphere amplify that until a few paths take another branch; next to bright textures such a path moves a pixel visibly, so the frame is
-    compared by the share of affected pixels and the median difference, with a loose RMSE bound."""
+    colour on meshes and spheres, an alpha channel and a 0.7 opacity in the stochastic alpha tests (include/material.h:32-93)."""
     scene = pc.load_scene("textures")
     rt = gi.RayTracer(0).setScene(scene)
     rt.set_render_mode(mode)
     pc.check_emission(rt, scene, 600)
-    rmse, img, ref = pc.check_render(rt, scene, 80, 60, 8, 1500, tol=1e-3)
+    rmse, img, ref = pc.check_render(rt, scene, 80, 60, 8, 1500, tol=1e-5)          # measured 3.2e-7
     assert img.mean() > 0.01 and np.median(np.abs(img - ref)) < 1e-12
-    assert (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.05
+    assert (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.02                      # measured 0.5 % of the pixels
 
 
 def test_textured_cornell_scene_wide_and_per_node():
     """Textures together with the wide octree records, the LDS-resident top of the tree and refraction (scenes/textures/cornell_tex.scn,
-    3 218 triangles): against the oracle, and wide == per-node bit for bit."""
+    3 218 triangles, a glass teapot in a box with bright textured walls): against the oracle, and wide == per-node bit for bit.
+    This is the scene where a diverted path costs most (it lands on a bright texture instead of a dark one): at 8 spp 6 of 5 184 pixels
+    differ and the frame RMSE is 2.3e-4; the contract is quoted at 256 spp, where one path is 1/256 of a pixel -- at 64 spp the same
+    frame is inside 1e-4."""
     scene = pc.load_scene("cornell_tex")
     rt = gi.RayTracer(0).setScene(scene)
-    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, tol=1e-3)   # glass teapot: a few chaotic specular chains differ (see above)
+    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 64, 5000, tol=1e-4)
+    print("cornell_tex 64 spp rmse", rmse, "pixels off", (np.abs(img - ref).max(axis=2) > 1e-9).mean())
     assert img.mean() > 0.01 and np.median(np.abs(img - ref)) < 1e-12
-    assert (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.01
+    assert (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.02
+    rmse8, img8, ref8 = pc.check_render(rt, scene, 96, 54, 8, 5000, tol=1e-3)       # measured 2.3e-4, 0.12 % of the pixels
+    assert (np.abs(img8 - ref8).max(axis=2) > 1e-9).mean() < 0.005
     assert rt.set_wide_nodes(True)
     a = rt.run(96, 54, min_samples=8, max_samples=8)
     assert not rt.set_wide_nodes(False)
@@ -85,8 +103,8 @@ def test_large_procedural_scene_matches_oracle():
     scene = big_scene.build(40, 80, textured=True)
     rt = gi.RayTracer(0).setScene(scene)
     assert rt.set_wide_nodes(True)
-    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, tol=1e-3)
-    assert img.mean() > 0.01 and np.median(np.abs(img - ref)) < 1e-12 and (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.02
+    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, tol=1e-9)          # measured 1.4e-17
+    assert img.mean() > 0.01
 
 
 def test_glass_teapot_scene_matches_oracle():
@@ -141,15 +159,14 @@ def test_emission_identical_to_oracle(setup):
 def test_render_matches_oracle(setup, adaptive, mode):
     name, scene, rt, fx = setup
     rt.set_render_mode(mode)
-    glassy = name in ("textures_opaque", "caustics_02")   # glass next to bright surfaces: see test_textured_scene_matches_oracle
     try:
-        rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, adaptive, tol=1e-3 if glassy else pc.RMSE_TOL, spp_mismatch=0.05 if glassy else 0.0)
+        rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 5000, adaptive)    # per-pixel sample counts of the adaptive loop: exact, every scene
     finally:
         rt.set_render_mode("wavefront")
-    if glassy:
-        assert (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.05 and np.median(np.abs(img - ref)) < 1e-12, rmse
+    if name == "textures_opaque":     # glass sphere next to bright textures (see above): measured 2.4e-6 / 6.9e-7 (fixed / adaptive), 0.6-2.2 % of the pixels
+        assert rmse < 1e-5 and (np.abs(img - ref).max(axis=2) > 1e-9).mean() < 0.05 and np.median(np.abs(img - ref)) < 1e-12, rmse
     else:
-        assert rmse < 1e-9, rmse      # far inside the 1e-4 contract: any larger value means a diverged path
+        assert rmse < 1e-9, rmse      # far inside the 1e-4 contract: any larger value means a diverged path (caustics_02, glass sphere mesh: 8e-18)
 
 
 def test_wavefront_small_pool_many_rounds(setup):
@@ -290,6 +307,67 @@ def test_full_size_properties(name, w, h, spp, photons):
         o.set_photons(ph).build_photon_map()
         ref = o.render(w, h, spp, y0=h // 2, y1=h // 2 + 4)["lin"][h // 2:h // 2 + 4]
         assert np.sqrt(((a[h // 2:h // 2 + 4] - ref) ** 2).mean()) < 1e-9
+
+
+def test_eight_bit_frame_matches_oracle():
+    """the display frame -- gamma 2.2, clamp, truncating (int)(255 c) (include/raytracer.h:150-157, include/image.h:14-16) --
+    of the product's radiance against the oracle's bytes (whose sink is pinned to the reference's own Image, kat_pixel, and to its run()
+    frames).  The caustics frame has pixels with a negative channel (col * dot(photon.dir, dir) < 0): the reference's pow() makes them NaN and
+    its cast 0."""
+    scene = pc.load_scene("caustics")
+    rt = gi.RayTracer(0).setScene(scene)
+    o = pc.oracle_for(scene)
+    ph, _ = rt.tracePhotons(5000)
+    o.set_photons(ph).build_photon_map()
+    for kw in (dict(min_samples=4, max_samples=4), dict(min_samples=4, max_samples=16, noise_thresh=0.0015)):
+        lin = rt.run(96, 54, **kw)
+        ref = o.render(96, 54, kw["min_samples"], kw["max_samples"], kw.get("noise_thresh", 0.0015), want_u8=True)
+        assert (lin < 0).any(), "the frame should hold pixels with a negative channel"
+        got = gi.to_rgb8(lin)
+        assert got[(lin < 0)].max() == 0
+        assert np.array_equal(got, ref["u8"])
+
+
+def test_config5_standin_fog_photons_large_tree():
+    """BASELINE config 5 stand-in (sponza.obj is absent upstream): a large procedural tree (tools/big_scene.py), a HeightFog slab
+    (include/atmosphere.h:30-83) and a photon map together.  Small frame against the oracle; then the 3840x2160 frame through the
+    size-independent properties, a 4-row window against the oracle, and sample index 478 -- the last one a 4K pixel can address before the
+    reference's 32-bit Halton index wraps (include/halton_enum.h:41,109-113)."""
+    import sys
+    sys.path.insert(0, os.path.join(pc.ROOT, "tools"))
+    import big_scene
+    scene = big_scene.build(40, 80, fog=True)
+    assert scene.desc().n_fog == 1 and scene.desc().n_node > 20000
+    rt = gi.RayTracer(0).setScene(scene)
+    for mode in ("wavefront", "megakernel"):
+        rt.set_render_mode(mode)
+        rmse, img, ref = pc.check_render(rt, scene, 96, 54, 8, 20000, tol=1e-9)
+        rmse_a, _, _ = pc.check_render(rt, scene, 64, 36, 4, 20000, adaptive=True, tol=1e-9)
+        print("config5 stand-in", mode, rmse, rmse_a)
+    rt.set_render_mode("wavefront")
+    assert len(scene.photon_tables()["photons"]) > 5000
+    w, h, spp = 3840, 2160, 2
+    a, na = rt.run(w, h, min_samples=spp, max_samples=spp, want_spp=True)
+    assert (na == spp).all() and np.isfinite(a).all()
+    assert np.array_equal(a, rt.run(w, h, min_samples=spp, max_samples=spp))                 # deterministic
+    frame = np.zeros_like(a)
+    for rank in range(8):
+        frame[pc.stripe_rows(h, 16, rank, 8)] = rt.run(w, h, min_samples=spp, max_samples=spp, stripe_h=16, rank=rank, world=8)
+    assert np.array_equal(frame, a)                                                           # the 8-GPU decomposition
+    o = pc.oracle_for(scene)
+    o.set_photons(scene.photon_tables()["photons"]).build_photon_map()
+    rows = slice(h // 2 + 200, h // 2 + 204)
+    ref = o.render(w, h, spp, y0=rows.start, y1=rows.stop)["lin"][rows]
+    assert np.sqrt(((a[rows] - ref) ** 2).mean()) < 1e-9
+    # samples 477 and 478 of a 4K pixel (the last addressable ones) and 479.. (wrapped, as in the reference): the index arithmetic is pinned
+    # bit-exactly by the halton fixture (test_halton_device_tables); here the radiance of those samples against the oracle
+    rays, idx = [], []
+    for s_ in (477, 478, 479, 1023):
+        for (x, y) in ((0, 0), (1917, 1083), (3839, 2159)):
+            i, r = o.primary_ray(w, h, s_, x, y)
+            rays.append(r); idx.append(i)
+    got, want = rt.radiance(np.array(rays), np.array(idx, np.uint32)), o.radiance(np.array(rays), np.array(idx, np.uint32), rt.seed)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
 
 
 def test_headless_cli_writes_the_display_frame(tmp_path):

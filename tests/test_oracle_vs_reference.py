@@ -66,6 +66,19 @@ def test_samplers_bit_exact(golden):
         L.gio_reflect(P(r[0:3]), P(r[3:6]), o.ctypes.data_as(ol.c_dp)); assert o.tobytes() == r[10:13].tobytes()
 
 
+def test_pixel_sink_known_answers(golden):
+    """a-19: gamma 2.2 + glm::clamp + Image::setPixel as the reference's own Image stored them (kat_pixel: negative channels, values above
+    1, values one ulp either side of the k/255 thresholds) -- for the oracle's sink and for the product's host-side sink gih_to_rgb8."""
+    import gi_raytracer_amd as gi
+    k, L = golden("kat")["kat_pixel"], ol.lib()
+    lin = np.ascontiguousarray(k[:, :3]).reshape(-1)
+    out = np.zeros(len(lin), np.uint8)
+    L.gio_pixel8(len(lin), lin.ctypes.data_as(ol.c_dp), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert np.array_equal(out.reshape(-1, 3), k[:, 3:].astype(np.uint8))
+    assert (k[:, :3] < 0).any() and (k[:, :3] > 1).any()
+    assert np.array_equal(gi.to_rgb8(k[:, :3]), k[:, 3:].astype(np.uint8))
+
+
 def test_tri_box_overlap(golden):
     k, L = golden("kat")["kat_tribox"], ol.lib()
     got = [L.gio_tri_box_overlap(P(r[0:3]), P(r[3:6]), P(r[6:15])) for r in k]
