@@ -468,6 +468,34 @@ GI_HD bool tri_hit(const Tri& g, const Ray& ray, double& u, double& v, double& t
 
 struct HitRec { V3 pos; double u, v; int32_t tri; uint32_t mf; double tu, tv; };   // mf = LeafTri::matflags of the hit (material << 3 | flags)   // u, v barycentric; tu, tv = the reference's `uv` (GI_FEAT_TEX only)
 
+// Wave-uniform leaves.  When every active lane of a wave stands on the SAME leaf (primary rays of one 8x8 tile, shadow rays towards one
+// light) the leaf's records are fetched once per wave through the scalar cache (s_load into SGPRs -- a load from the constant address
+// space at a wave-uniform address) instead of once per lane through the vector memory path: the 64 identical copies of an 80-byte
+// record were what kept the L1 -> VGPR path as busy as the VALU.  The tests then read the record as SGPR operands; same arithmetic,
+// same order, same bits.  Device code only (the CPU build of these functions has no waves).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GI_WAVE_UNIFORM_LEAVES 1
+GI_HD bool leaf_is_wave_uniform(int32_t first, int32_t cnt, int32_t& first_u, int32_t& cnt_u)
+{
+    first_u = __builtin_amdgcn_readfirstlane(first);
+    cnt_u = __builtin_amdgcn_readfirstlane(cnt);
+    return __ballot(first != first_u || cnt != cnt_u) == 0ull;
+}
+GI_HD LeafTri leaf_tri_scalar(const LeafTri* rec)   // rec is wave-uniform
+{
+    typedef const __attribute__((address_space(4))) double* KD;
+    typedef const __attribute__((address_space(4))) int32_t* KI;
+    const KD d = (KD)(reinterpret_cast<const double*>(rec));
+    const KI w = (KI)(reinterpret_cast<const int32_t*>(rec));
+    LeafTri g;
+    g.p0[0] = d[0]; g.p0[1] = d[1]; g.p0[2] = d[2];
+    g.e1[0] = d[3]; g.e1[1] = d[4]; g.e1[2] = d[5];
+    g.e2[0] = d[6]; g.e2[1] = d[7]; g.e2[2] = d[8];
+    g.tri = w[18]; g.matflags = (uint32_t)w[19];
+    return g;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ textures (include/material.h:10-81)
 GI_HD const unsigned char* tex_pixel(const Scene& S, const TexD& x, double tu, double tv)   // image.pixelColor(...), include/material.h:65
 {
@@ -698,6 +726,12 @@ GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rn
                 if (box_contains(lmin, lmax, hp)) term = true;
             }
         };
+#ifdef GI_WAVE_UNIFORM_LEAVES
+        int32_t first_u, cnt_u;
+        if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
+            for (int32_t j = 0; j < cnt_u; j++) test(leaf_tri_scalar(S.leaf_tris + first_u + j));
+        } else
+#endif
         for (int32_t j = 0; j < cnt; j += 2) {
             const LeafTri g0 = S.leaf_tris[first + j];
             const LeafTri g1 = S.leaf_tris[first + (j + 1 < cnt ? j + 1 : j)];
@@ -719,21 +753,35 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
             int32_t lnode = 0, first = 0, cnt = 0;
             int lslot = 0;
             if (!wwalk_next_leaf(W, k, ray, wr, 0.0, tmax, lnode, lslot, first, cnt)) break;
-            for (int32_t j = 0; j < cnt; j++) {
-                const LeafTri& g = S.leaf_tris[first + j];
+            auto blocks = [&](const LeafTri& g) -> bool {
                 const int32_t ti = g.tri;
                 double u, v;
                 V3 hp;
-                if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) continue;
+                if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return false;
                 if (!(g.matflags & 2u)) {
                     const Mat& m = S.mats[g.matflags >> 3];
                     double alpha = m.opacity * 1.0;
                     if (FEAT & GI_FEAT_TEX) { double cu = 0, cv = 0; ent_uv(S, g, g.matflags, ti, u, v, hp, cu, cv); alpha = mat_alpha(S, m, cu, cv); }
-                    if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) continue;
+                    if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return false;
                 }
-                double ts = len2(hp - ray.o);
-                if ((ts < mt) && (ts > 0)) return false;
+                const double ts = len2(hp - ray.o);
+                return (ts < mt) && (ts > 0);
+            };
+#ifdef GI_WAVE_UNIFORM_LEAVES
+            int32_t first_u, cnt_u;
+            if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
+                bool hit = false;
+                for (int32_t j = 0; j < cnt_u; j++) {     // wave-uniform trip count: the record address stays scalar
+                    const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
+                    if (!hit) hit = blocks(g);
+                    if (__ballot(!hit) == 0ull) break;
+                }
+                if (hit) return false;
+                continue;
             }
+#endif
+            for (int32_t j = 0; j < cnt; j++)
+                if (blocks(S.leaf_tris[first + j])) return false;
         }
     }
     if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:308-316

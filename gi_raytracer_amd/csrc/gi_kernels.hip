@@ -406,49 +406,79 @@ __device__ __forceinline__ void st_finish(const PathRec& p, uint32_t slot, const
     if (finished) q_free[at] = slot;
 }
 
-// refill the first n_start free slots (q_free == nullptr: slots 0..n_start-1) with samples id_base .. id_base + n_start - 1;
-// the new paths are q_new[0 .. n_start).  Sample ids are consecutive per lane, i.e. neighbouring pixels of one sample index.
-__global__ __launch_bounds__(GI_BLOCK) void k_st_regen(Scene S, Frame F, PathRec* pool, unsigned long long* slot_sample, const uint32_t* q_free, uint32_t n_start,
-                                                      unsigned long long id_base, unsigned long long sample_begin, int s_begin, uint32_t n_pix, uint32_t* q_new)
-{
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_start; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = q_free ? q_free[i] : i;
-        const unsigned long long id = id_base + i;
-        // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
-        const uint32_t rel = (uint32_t)(id - sample_begin), srel = rel / n_pix;
-        int x, ly;
-        st_pixel_xy(F, rel - srel * n_pix, x, ly);
-        slot_sample[slot] = id;
-        uint32_t idx;
-        Ray ray = primary_ray(S, F, s_begin + (int)srel, x, global_row(F, ly), idx);
-        path_begin_lean(pool[slot], ray, idx);
-        q_new[i] = slot;
-    }
-}
-
 #define GI_TRACE_BLOCK 1024
 #define GI_SHADE_BLOCK 512
+// New samples are started inside the trace kernel (path regeneration fused into the first trace of the path): item i < g.n_gen takes the
+// i-th free slot and sample id g.id_base + i, builds its primary ray in registers and traces it at once -- a primary ray that misses
+// never exists in memory (its radiance goes straight to lbuf and the slot straight back to the free list), one that hits is stored
+// together with its hit.  Sample ids are consecutive per lane = neighbouring pixels of one 8x8 tile, so these waves are coherent.
+struct GenArgs {
+    Frame F;
+    const uint32_t* q_free;           // free slots to fill (nullptr: slots 0 .. n_gen - 1)
+    uint32_t n_gen, n_pix;
+    unsigned long long id_base, sample_begin;
+    int s_begin;
+};
 template <int FEAT, int WIDE>
-__global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
-                                                       const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
+__global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, unsigned long long* slot_sample, unsigned long long sample0,
+                                                       GenArgs g, const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf)
 {
     const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_in = n_a + n_b;
+    const uint32_t n_in = g.n_gen + n_a + n_b;
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = i0 + lane;
         bool hit = false, fin = false;
         uint32_t slot = 0;
         if (i < n_in) {
-            slot = i < n_a ? q_a[i] : q_b[i - n_a];
+            const bool gen = i < g.n_gen;
+            Ray ray;
+            uint32_t stream;
+            int32_t depth = 0;
+            unsigned long long id = 0;
+            if (gen) {
+                slot = g.q_free ? g.q_free[i] : i;
+                id = g.id_base + i;
+                // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
+                const uint32_t rel = (uint32_t)(id - g.sample_begin), srel = rel / g.n_pix;
+                int x, ly;
+                st_pixel_xy(g.F, rel - srel * g.n_pix, x, ly);
+                ray = primary_ray(S, g.F, g.s_begin + (int)srel, x, global_row(g.F, ly), stream);
+            } else {
+                slot = i - g.n_gen < n_a ? q_a[i - g.n_gen] : q_b[i - g.n_gen - n_a];
+                const PathRec& p = pool[slot];
+                ray = make_ray_exact(ld3(p.o), ld3(p.d));
+                stream = p.stream; depth = p.depth;
+            }
+            HitRec h;
+            if (depth > GI_MAX_DEPTH) fin = true;            // radiance() returns 0 past MAX_DEPTH
+            else {
+                Rng rng = rng_make(seed, stream);
+                rng.depth = (uint32_t)depth;
+                hit = trace_nodes<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, h, nullptr);
+                fin = !hit;
+            }
             PathRec& p = pool[slot];
-            if (p.depth > GI_MAX_DEPTH) fin = true;            // radiance() returns 0 past MAX_DEPTH
-            else { hit = stage_trace_nodes<FEAT>(S, N, p, seed, nullptr); fin = !hit; }
+            if (hit) {
+                if (gen) { path_begin_lean(p, ray, stream); slot_sample[slot] = id; }
+                p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
+                p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.pad = h.mf;
+                if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
+            } else {
+                // the path ends here: a miss adds T * ambient (stage_trace_nodes), past MAX_DEPTH nothing; L goes straight to the radiance buffer
+                const bool first = depth == 0;   // L = 0, T = 1 by definition (PathRec)
+                V3 L = first ? v3(0, 0, 0) : ld3(p.L);
+                if (depth <= GI_MAX_DEPTH) L = L + (first ? v3(1, 1, 1) : ld3(p.T)) * ld3(S.ambient);
+                if (!gen) id = slot_sample[slot];
+                double* o = lbuf + (id - sample0) * 3;
+                o[0] = L.x; o[1] = L.y; o[2] = L.z;
+            }
         }
         const uint32_t at = wave_append(&ctl->n_shade, hit);
         if (hit) q_shade[at] = slot;
-        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free, &ctl->n_free, fin);
+        const uint32_t af = wave_append(&ctl->n_free, fin);
+        if (fin) q_free[af] = slot;
     }
 }
 
@@ -1175,13 +1205,13 @@ static void stage_end(gi_ctx* c)
     c->ev_used += 2;
 }
 
-struct StreamGrids { int init = 0, regen = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0; };
+struct StreamGrids { int init = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0; };
 static const size_t kLdsNodes = (size_t)GI_LDS_NODES * sizeof(TNode);
 static const StreamGrids& stream_grids(gi_ctx* c)
 {
     static StreamGrids g;
     if (!g.trace) {
-        g.init = grid_for(c, (const void*)k_wf_init); g.regen = grid_for(c, (const void*)k_st_regen); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
+        g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
         g.shade = grid_for(c, (const void*)k_st_shade<7, 1>, kLdsNodes, GI_SHADE_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
         g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
@@ -1210,7 +1240,7 @@ static int stream_alloc(gi_ctx* c, uint32_t P)
 // starts up to n_free new paths in the slots of the free list qf (nullptr: slots 0 .. n_free - 1), writes them to c->d_qs[0] and
 // returns how many; `exhausted` tells that it will start no more.  A finished path leaves its radiance at lbuf[slot_sample[slot] - sample0].
 static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, double* lbuf, uint32_t n_free,
-                         const std::function<uint32_t(uint32_t, const uint32_t*)>& refill, const bool& exhausted,
+                         const std::function<uint32_t(uint32_t, const uint32_t*, GenArgs&)>& refill, const bool& exhausted,
                          volatile const int* cancel, int& launches)
 {
     const StreamGrids& G = stream_grids(c);
@@ -1228,7 +1258,13 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
     int ping = 0;
     for (;;) {
         if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
-        const uint32_t n_new = refill(n_free, qf);
+        // new paths of this pass: either samples the trace kernel starts itself (gen, streaming frames) or paths a caller prepared in
+        // the new-path queue (adaptive rounds) -- refill() says which by filling gen.n_gen or returning a count
+        GenArgs gen;
+        memset(&gen, 0, sizeof gen);
+        gen.F = F;
+        const uint32_t n_prepared = refill(n_free, qf, gen);
+        const uint32_t n_new = n_prepared + gen.n_gen;
         if (n_new + n_cont == 0) break;
         uint32_t* qcont_out = q_cont[ping];
         const uint32_t* qcont_in = q_cont[ping ^ 1];
@@ -1254,7 +1290,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
         uint32_t* qfree_out = q_free[ping];
         const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0, tex = c->S.n_tex > 0;
-        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_new, n_new, qcont_in, n_cont, ctl,
+        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, ctl,
                            q_shade, qfree_out, lbuf); stage_end(c);
         stage_begin(c, STG_SHADE); hipLaunchKernelGGL(tex ? (wide ? k_st_shade<7, 1> : k_st_shade<7, 0>) : wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
                            qfree_out, lbuf); stage_end(c);
@@ -1325,15 +1361,12 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         const unsigned long long sample0 = (unsigned long long)s0 * n_pix, sample_end = (unsigned long long)(s0 + ns) * n_pix;
         unsigned long long next = sample0;
         bool exhausted = false;
-        auto refill = [&](uint32_t n_free, const uint32_t* qf) -> uint32_t {   // path regeneration: free slots take the next samples
+        auto refill = [&](uint32_t n_free, const uint32_t* qf, GenArgs& gen) -> uint32_t {   // path regeneration: free slots take the next samples
             const uint32_t n_new = (uint32_t)std::min<unsigned long long>(n_free, sample_end - next);
-            if (n_new > 0) {
-                stage_begin(c, STG_REGEN); hipLaunchKernelGGL(k_st_regen, dim3(G.regen), dim3(GI_BLOCK), 0, st, c->S, F, c->d_pool.p, c->d_slot_sample.p, qf, n_new, next, sample0, s0, n_pix, c->d_qs[0].p); stage_end(c);
-                launches++;
-                next += n_new;
-            }
+            gen.q_free = qf; gen.n_gen = n_new; gen.n_pix = n_pix; gen.id_base = next; gen.sample_begin = sample0; gen.s_begin = s0;
+            next += n_new;
             exhausted = next >= sample_end;
-            return n_new;
+            return 0;                                                                          // nothing prepared: the trace kernel starts them
         };
         rc = stream_passes(c, F, sample0, c->d_lbuf.p, P, refill, exhausted, cancel, launches);   // pass 0: every slot is free
         if (rc) return rc;
@@ -1388,7 +1421,7 @@ static int render_adaptive(gi_ctx* c, const Frame& F, void* d_out, int out_is_f6
         HIP_TRY(c, hipStreamSynchronize(st));
         uint32_t pending = c->h_wfcnt[0];          // paths started by this round, already in the new-path queue
         const bool exhausted = true;
-        auto refill = [&](uint32_t, const uint32_t*) -> uint32_t { const uint32_t n = pending; pending = 0; return n; };
+        auto refill = [&](uint32_t, const uint32_t*, GenArgs&) -> uint32_t { const uint32_t n = pending; pending = 0; return n; };
         rc = stream_passes(c, F, 0ull, c->d_lbuf.p, 0u, refill, exhausted, cancel, launches);
         if (rc) return rc;
         stage_begin(c, STG_ACCUM);
