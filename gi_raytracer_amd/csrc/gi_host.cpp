@@ -194,6 +194,54 @@ bool tri_overlaps_box(D3 c, D3 half, D3 t0, D3 t1, D3 t2)
 }
 
 // glm::eulerAngleXYZ upper 3x3 (3rd_party/glm/gtx/euler_angles.inl:135-167), column-major m[col][row]
+// Entity::boundingBox and Entity::intersect(BoundingBox) of the two entity kinds (0 triangle: three vertices; 1 sphere: centre = v[0], radius = v[1].x)
+const double kEntEps = 0.00001;   // EPSILON, include/util.h:18
+// triangle::boundingBox, include/entities.h:530-557: the upper corner grows by EPSILON after EVERY vertex; sphere::boundingBox, :103-106
+Aabb entity_box(int kind, const D3 v[3])
+{
+    Aabb b;
+    if (kind == 1) {
+        const D3 c = v[0];
+        const double rad = v[1].x;
+        b.lo = mk(c.x + rad * -1, c.y + rad * -1, c.z + rad * -1);
+        b.hi = mk(c.x + rad * 1, c.y + rad * 1, c.z + rad * 1);
+        return b;
+    }
+    b.lo = mk(INFINITY, INFINITY, INFINITY); b.hi = mk(-INFINITY, -INFINITY, -INFINITY);
+    for (int k = 0; k < 3; k++) {
+        const D3 p = v[k];
+        if (p.x < b.lo.x) b.lo.x = p.x;
+        if (p.x > b.hi.x) b.hi.x = p.x;
+        if (p.y < b.lo.y) b.lo.y = p.y;
+        if (p.y > b.hi.y) b.hi.y = p.y;
+        if (p.z < b.lo.z) b.lo.z = p.z;
+        if (p.z > b.hi.z) b.hi.z = p.z;
+        b.hi.x += kEntEps; b.hi.y += kEntEps; b.hi.z += kEntEps;
+    }
+    return b;
+}
+// triangle::intersect(BoundingBox), include/entities.h:522-528; sphere::intersect(BoundingBox), :108-141 (squared distance centre-box <= rad^2)
+bool entity_in_cell(int kind, const D3 v[3], const Aabb& cell)
+{
+    if (kind == 1) {
+        const D3 c = v[0];
+        const double rad = v[1].x;
+        double sq = 0.0;
+        for (int ax = 0; ax < 3; ax++) {
+            const double q = comp(c, ax), lo = comp(cell.lo, ax), hi = comp(cell.hi, ax);
+            double out = 0;
+            if (q < lo) { const double val = (lo - q); out += val * val; }
+            if (q > hi) { const double val = (q - hi); out += val * val; }
+            sq += out;
+        }
+        return sq <= (rad * rad);
+    }
+    Aabb g;
+    g.lo = mk(cell.lo.x - kEntEps, cell.lo.y - kEntEps, cell.lo.z - kEntEps);
+    g.hi = mk(cell.hi.x + kEntEps, cell.hi.y + kEntEps, cell.hi.z + kEntEps);
+    return tri_overlaps_box(centre(g), mk(ext_x(g) / 2, ext_y(g) / 2, ext_z(g) / 2), v[0], v[1], v[2]);
+}
+
 struct M3 { double m[3][3]; };
 M3 euler_xyz(double t1, double t2, double t3)
 {
@@ -298,51 +346,8 @@ struct gih_scene {
 
     D3 vert(int t, int k) const { const double* p = &tri_pos[(size_t)t * 9 + k * 3]; return mk(p[0], p[1], p[2]); }
 
-    // triangle::boundingBox, include/entities.h:530-557: the upper corner grows by EPSILON after EVERY vertex
-    Aabb triangle_box(int t) const
-    {
-        Aabb b;
-        if (ent_kind[t] == 1) {   // sphere::boundingBox, include/entities.h:103-106
-            const D3 c = vert(t, 0);
-            const double rad = vert(t, 1).x;
-            b.lo = mk(c.x + rad * -1, c.y + rad * -1, c.z + rad * -1);
-            b.hi = mk(c.x + rad * 1, c.y + rad * 1, c.z + rad * 1);
-            return b;
-        }
-        b.lo = mk(INFINITY, INFINITY, INFINITY); b.hi = mk(-INFINITY, -INFINITY, -INFINITY);
-        for (int k = 0; k < 3; k++) {
-            const D3 v = vert(t, k);
-            if (v.x < b.lo.x) b.lo.x = v.x;
-            if (v.x > b.hi.x) b.hi.x = v.x;
-            if (v.y < b.lo.y) b.lo.y = v.y;
-            if (v.y > b.hi.y) b.hi.y = v.y;
-            if (v.z < b.lo.z) b.lo.z = v.z;
-            if (v.z > b.hi.z) b.hi.z = v.z;
-            b.hi.x += kEps; b.hi.y += kEps; b.hi.z += kEps;
-        }
-        return b;
-    }
-    // triangle::intersect(BoundingBox), include/entities.h:522-528
-    bool triangle_in_cell(int t, const Aabb& cell) const
-    {
-        if (ent_kind[t] == 1) {   // sphere::intersect(BoundingBox), include/entities.h:108-141: squared distance centre-box <= rad^2
-            const D3 c = vert(t, 0);
-            const double rad = vert(t, 1).x;
-            double sq = 0.0;
-            for (int ax = 0; ax < 3; ax++) {
-                const double v = comp(c, ax), lo = comp(cell.lo, ax), hi = comp(cell.hi, ax);
-                double out = 0;
-                if (v < lo) { const double val = (lo - v); out += val * val; }
-                if (v > hi) { const double val = (v - hi); out += val * val; }
-                sq += out;
-            }
-            return sq <= (rad * rad);
-        }
-        Aabb g;
-        g.lo = mk(cell.lo.x - kEps, cell.lo.y - kEps, cell.lo.z - kEps);
-        g.hi = mk(cell.hi.x + kEps, cell.hi.y + kEps, cell.hi.z + kEps);
-        return tri_overlaps_box(centre(g), mk(ext_x(g) / 2, ext_y(g) / 2, ext_z(g) / 2), vert(t, 0), vert(t, 1), vert(t, 2));
-    }
+    Aabb triangle_box(int t) const { const D3 v[3] = {vert(t, 0), vert(t, 1), vert(t, 2)}; return entity_box(ent_kind[t], v); }
+    bool triangle_in_cell(int t, const Aabb& cell) const { const D3 v[3] = {vert(t, 0), vert(t, 1), vert(t, 2)}; return entity_in_cell(ent_kind[t], v, cell); }
 
     void push_triangle(const D3 p[3], const D3 n[3], const double uv[6], int mat)
     {
@@ -641,12 +646,13 @@ struct gih_scene {
     // new HeightFog(pos, size, col, density, scatter, noiseScale), include/atmosphere.h:37-47: the noise grid has
     // (sx+1)(sy+1)(sz+1) noiseScale^3 values; the reference draws them from time-seeded drand(), here they are given or come
     // from the counter RNG (splitmix64 of seed and index)
-    int add_height_fog(const double* q, const double* grid, int n_grid, unsigned long long seed)
+    int add_height_fog(const double* q, const double* grid, int n_grid, unsigned long long seed, bool any_size = false)
     {
         const int ns = (int)q[11];
         const double want = (q[3] + 1) * (q[4] + 1) * (q[5] + 1) * std::pow((double)ns, 3);
         int n = 0;
         for (int i = 0; i < want; i++) n++;   // the constructor's loop: for (int i = 0; i < (double)N; i++)
+        if (grid && any_size) n = n_grid;     // an entity that carries its grid (the C++ HeightFog): taken as it is
         if (n <= 0) { err = "heightFog: empty noise grid"; return -2; }
         if (grid && n_grid != n) { err = "heightFog: noise grid size does not match (sx+1)(sy+1)(sz+1) scale^3"; return -2; }
         fog.insert(fog.end(), q, q + 12);
@@ -681,6 +687,13 @@ int gih_load_scn(gih_scene* s, const char* path)
 {
     if (!s || !path) return -1;
     return s->load_scn(path);
+}
+
+int gih_load_obj(gih_scene* s, const char* path, const double* pos3, const double* rot3, int32_t mat_idx)
+{
+    if (!s || !path || !pos3 || !rot3) return -1;
+    if (mat_idx < 0 || mat_idx >= (int)(s->mats.size() / 9)) { s->err = "load_obj: material index out of range"; return -2; }
+    return s->load_obj(path, mk(pos3[0], pos3[1], pos3[2]), mk(rot3[0], rot3[1], rot3[2]), mat_idx);
 }
 
 int gih_add_material(gih_scene* s, const double* m)
@@ -751,6 +764,12 @@ int gih_add_height_fog(gih_scene* s, const double* params12, const double* grid,
 {
     if (!s || !params12) return -1;
     return s->add_height_fog(params12, grid, n_grid, seed);
+}
+
+int gih_add_height_fog_grid(gih_scene* s, const double* params12, const double* grid, int32_t n_grid)
+{
+    if (!s || !params12 || !grid || n_grid <= 0) return -1;
+    return s->add_height_fog(params12, grid, n_grid, 0, true);
 }
 
 int gih_add_light(gih_scene* s, const double* pos3, const double* col3, double rad)
@@ -831,6 +850,14 @@ int gih_build_photon_map(gih_scene* s, int32_t n, const double* photons)
     return s->build_photon_map(n, photons);
 }
 
+int gih_build_photon_map_in_box(gih_scene* s, const double* box6, int32_t n, const double* photons)
+{
+    if (!s || !box6 || n < 0 || (n && !photons)) return -1;
+    s->root_box.lo = mk(box6[0], box6[1], box6[2]);
+    s->root_box.hi = mk(box6[3], box6[4], box6[5]);
+    return s->build_photon_map(n, photons);
+}
+
 int gih_get_photon_desc(const gih_scene* s, gi_photon_map_desc* d)
 {
     if (!s || !d) return -1;
@@ -840,6 +867,46 @@ int gih_get_photon_desc(const gih_scene* s, gi_photon_map_desc* d)
     d->n_node = (int32_t)(s->pm_bbox.size() / 6);
     d->node_bbox = s->pm_bbox.data(); d->node_child = s->pm_child.data(); d->node_off = s->pm_off.data(); d->node_idx = s->pm_idx.data();
     return 0;
+}
+
+// ---- single-object forms of what the tree builder and the loader do, for the C++ entity classes (include/gi/entities.h, atmosphere.h)
+int gih_entity_bbox(int32_t kind, const double* pos9, double* out6)
+{
+    if (!pos9 || !out6 || (kind != 0 && kind != 1)) return -1;
+    const D3 v[3] = {mk(pos9[0], pos9[1], pos9[2]), mk(pos9[3], pos9[4], pos9[5]), mk(pos9[6], pos9[7], pos9[8])};
+    const Aabb b = entity_box(kind, v);
+    out6[0] = b.lo.x; out6[1] = b.lo.y; out6[2] = b.lo.z; out6[3] = b.hi.x; out6[4] = b.hi.y; out6[5] = b.hi.z;
+    return 0;
+}
+
+int gih_entity_overlaps_box(int32_t kind, const double* pos9, const double* box6)
+{
+    if (!pos9 || !box6 || (kind != 0 && kind != 1)) return -1;
+    const D3 v[3] = {mk(pos9[0], pos9[1], pos9[2]), mk(pos9[3], pos9[4], pos9[5]), mk(pos9[6], pos9[7], pos9[8])};
+    Aabb cell;
+    cell.lo = mk(box6[0], box6[1], box6[2]); cell.hi = mk(box6[3], box6[4], box6[5]);
+    return entity_in_cell(kind, v, cell) ? 1 : 0;
+}
+
+int gih_box_mesh(const double* pos3, const double* size3, const double* rot3, double* out108)
+{
+    if (!pos3 || !size3 || !rot3 || !out108) return -1;
+    gih_scene s;
+    const double m[9] = {1, 1, 1, 0, 0, 0, 0, 0, 0};
+    s.mats.assign(m, m + 9);
+    s.add_box(mk(pos3[0], pos3[1], pos3[2]), mk(size3[0], size3[1], size3[2]), mk(rot3[0], rot3[1], rot3[2]), 0);
+    memcpy(out108, s.tri_pos.data(), 108 * sizeof(double));
+    return 12;
+}
+
+int gih_fog_grid(const double* params12, uint64_t seed, double* grid, int32_t n_grid)
+{
+    if (!params12) return -1;
+    gih_scene s;
+    if (s.add_height_fog(params12, nullptr, 0, seed) != 0) return -2;
+    const int n = (int)s.fog_grid.size();
+    if (grid) { if (n_grid != n) return -2; memcpy(grid, s.fog_grid.data(), (size_t)n * sizeof(double)); }
+    return n;
 }
 
 // gamma(color, 2.2), glm::clamp(color, 0, 1), Image::setPixel's (int)(255 c) (include/raytracer.h:150-157, include/util.h:94-97, include/image.h:14-16).

@@ -27,6 +27,10 @@ const char* gih_last_error(const gih_scene*);
  * Returns 0, or -1 when the .scn itself cannot be opened.                                                            */
 int gih_load_scn(gih_scene*, const char* path);
 
+/* replaces loadOBJ alone (include/meshLoader.cpp:18-99): the faces of one .obj, rotated (glm::eulerAngleXYZ) and moved, with material mat_idx;
+ * returns 0, or non-zero when the file cannot be opened / a face is not a v/vt/vn triple                                                */
+int gih_load_obj(gih_scene*, const char* path, const double* pos3, const double* rot3, int32_t mat_idx);
+
 /* programmatic construction = Octree::push_back (include/octree.cpp:25-50) */
 int gih_add_material(gih_scene*, const double* mat9);                 /* returns the material index */
 /* textures (include/material.h:10-81): kind and params8 as gi_scene_desc::tex_kind / tex_param; an image (kind 2) passes its
@@ -42,6 +46,7 @@ int gih_add_sphere(gih_scene*, const double* centre3, double radius, int32_t mat
 /* new HeightFog(pos, size, col, density, scatter, noiseScale) (include/atmosphere.h:37-47): params12 as in gi_scene_desc::fog;
  * grid = its (sx+1)(sy+1)(sz+1) scale^3 noise values, or NULL to fill them from the counter RNG with `seed`                  */
 int gih_add_height_fog(gih_scene*, const double* params12, const double* grid, int32_t n_grid, uint64_t seed);
+int gih_add_height_fog_grid(gih_scene*, const double* params12, const double* grid, int32_t n_grid);   /* a HeightFog that carries its own grid, any size */
 int gih_add_light(gih_scene*, const double* pos3, const double* col3, double rad);
 int gih_set_ambient(gih_scene*, const double* rgb3);
 
@@ -65,7 +70,18 @@ int gih_counts(const gih_scene*, int32_t* n_tri, int32_t* n_mat, int32_t* n_ligh
 /* replaces PhotonMap::push_back + rebuild (include/photonMap.cpp:24-47,137-192) over the scene's root box
  * (RayTracer::setScene, include/raytracer.h:38); photons [n][9] are copied                                           */
 int gih_build_photon_map(gih_scene*, int32_t n, const double* photons);
+/* the same in a box given by the caller -- PhotonMap(min, max) of the C++ surface (include/photonMap.h:33); the handle then serves as the map's container only */
+int gih_build_photon_map_in_box(gih_scene*, const double* box6, int32_t n, const double* photons);
 int gih_get_photon_desc(const gih_scene*, gi_photon_map_desc* out);
+
+/* Single-object forms of the builder's entity tests and of two generators, for the C++ entity classes (include/gi/entities.h, atmosphere.h):
+ * Entity::boundingBox / Entity::intersect(BoundingBox) of a triangle (kind 0: pos9 = three vertices) or sphere (kind 1: centre, radius in
+ * pos9[3]) (include/entities.h:103-141,522-557); boxMesh's 12 triangles [12][3][3] (include/entities.h:740-785); the noise grid of a
+ * HeightFog from the counter RNG (grid == NULL: returns the number of values).                                                       */
+int gih_entity_bbox(int32_t kind, const double* pos9, double* out6);
+int gih_entity_overlaps_box(int32_t kind, const double* pos9, const double* box6);   /* 1 / 0, negative on bad arguments */
+int gih_box_mesh(const double* pos3, const double* size3, const double* rot3, double* out108);
+int gih_fog_grid(const double* params12, uint64_t seed, double* grid, int32_t n_grid);
 
 /* replaces the 8-bit sink of RayTracer::run (include/raytracer.h:150-157: gamma(color, 2.2), glm::clamp) + Image::setPixel
  * (include/image.h:14-16: truncating (int)(255 c)): n_values linear channel values (float or double) -> bytes.  A negative value

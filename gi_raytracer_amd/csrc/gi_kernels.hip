@@ -792,6 +792,16 @@ __global__ __launch_bounds__(GI_BLOCK) void k_visible(Scene S, int n, const doub
     vis[i] = visible(S, sr, maxt, rng, 0, nullptr) ? 1 : 0;
 }
 
+__global__ __launch_bounds__(GI_BLOCK) void k_visible_rays(Scene S, int n, const double* rays, const double* mt, int32_t* vis)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rays + (size_t)i * 6;
+    Ray sr = make_ray_exact(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]));
+    Rng rng = rng_make(0, (uint32_t)i);
+    vis[i] = visible(S, sr, mt[i], rng, 0, nullptr) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(GI_BLOCK) void k_gather(Scene S, int n, const double* q, double* res3, int32_t* n_cand)
 {
     __shared__ float heap[GI_GATHER_K * GI_BLOCK];
@@ -1575,6 +1585,24 @@ int gi_visible(gi_ctx* c, int32_t n, const double* q, int32_t* vis)
     HIP_TRY(c, d_q.upload(std::vector<double>(q, q + (size_t)n * 6)));
     HIP_TRY(c, d_v.alloc(n));
     hipLaunchKernelGGL(k_visible, GI_GRID(n), 0, c->stream, c->S, n, d_q.p, d_v.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(vis, d_v.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_visible_rays(gi_ctx* c, int32_t n, const double* rays, const double* mt, int32_t* vis)
+{
+    if (!c || n < 0 || (n && (!rays || !mt || !vis))) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "visible: no scene uploaded");
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_r, d_m;
+    DevBuf<int32_t> d_v;
+    HIP_TRY(c, d_r.upload(std::vector<double>(rays, rays + (size_t)n * 6)));
+    HIP_TRY(c, d_m.upload(std::vector<double>(mt, mt + n)));
+    HIP_TRY(c, d_v.alloc(n));
+    hipLaunchKernelGGL(k_visible_rays, GI_GRID(n), 0, c->stream, c->S, n, d_r.p, d_m.p, d_v.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(vis, d_v.p, (size_t)n * 4, hipMemcpyDeviceToHost));

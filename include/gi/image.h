@@ -1,11 +1,29 @@
-// include/gi/image.h -- Qt-free mirror of include/image.h:7-29: RGB888 store with the reference's truncating (int)(255 c);
-// `rgb()` hands the bytes to a QImage (INTEGRATION.md shows the two-line adapter the Viewer needs).
+// include/gi/image.h -- the frame sink of the reference (include/image.h:7-29): RGB888 store written with the truncating (int)(255 c).
+// With -DGI_USE_QT the store is a QImage named `_image` with Viewer as a friend, exactly what include/viewer.h:43 reads, so the reference's
+// GUI compiles against this header unchanged; without Qt it is a plain byte array with the same methods (plus headless PPM / PFM writers).
 #pragma once
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <vector>
 #include "vec.h"
+#ifdef GI_USE_QT
+#include <QImage>
+#include <QColor>
+struct Image {
+    Image() = delete;
+    Image(int width, int height) : _image(width, height, QImage::Format_RGB888) { this->clear(); }
+    int width() const { return _image.width(); }
+    int height() const { return _image.height(); }
+    void setPixel(int x, int y, gi::dvec3 c) { _image.setPixel(x, y, QColor((int)(255 * c.x), (int)(255 * c.y), (int)(255 * c.z)).rgb()); }
+    void setPixel8(int x, int y, const uint8_t* rgb) { _image.setPixel(x, y, qRgb(rgb[0], rgb[1], rgb[2])); }
+    gi::dvec3 getPixel(int x, int y) const { const QRgb p = _image.pixel(x, y); return gi::dvec3(qRed(p) / 255., qGreen(p) / 255., qBlue(p) / 255.); }
+    void clear() { _image.fill(Qt::black); }
+  private:
+    QImage _image;
+    friend class Viewer;
+};
+#else
 struct Image {
     Image() = delete;
     Image(int width, int height) : _w(width), _h(height), _rgb((size_t)width * height * 3, 0) {}
@@ -16,6 +34,7 @@ struct Image {
         uint8_t* p = &_rgb[((size_t)y * _w + x) * 3];
         p[0] = (uint8_t)(int)(255 * c.x); p[1] = (uint8_t)(int)(255 * c.y); p[2] = (uint8_t)(int)(255 * c.z);
     }
+    void setPixel8(int x, int y, const uint8_t* rgb) { uint8_t* p = &_rgb[((size_t)y * _w + x) * 3]; p[0] = rgb[0]; p[1] = rgb[1]; p[2] = rgb[2]; }
     gi::dvec3 getPixel(int x, int y) const
     {
         const uint8_t* p = &_rgb[((size_t)y * _w + x) * 3];
@@ -36,6 +55,7 @@ struct Image {
     int _w, _h;
     std::vector<uint8_t> _rgb;
 };
+#endif
 // linear (pre-gamma, unclamped) radiance as a little-endian PFM, rows bottom to top as the format wants them
 inline bool gi_save_pfm(const char* path, const float* lin_rgb, int w, int h)
 {

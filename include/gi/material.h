@@ -55,6 +55,8 @@ struct imageTexture : texture {
         rgba.assign(px, px + (size_t)w * h * 4);
         gih_free(px);
     }
+    // the same from decoded pixels (RGBA8, rows top to bottom)
+    imageTexture(int w, int h, bool alpha, const unsigned char* px, gi::dvec2 t) : texture(gi::dvec3(0, 0, 0)), fname(""), tile(t), width(w), height(h), has_alpha(alpha), rgba(px, px + (size_t)w * h * 4) {}
     const unsigned char* pixel(const gi::dvec2& uv) const
     {
         const int x = std::abs((int)(uv.x * width * tile.x) % width);

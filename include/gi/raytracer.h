@@ -1,10 +1,17 @@
 // include/gi/raytracer.h -- drop-in for the reference's RayTracer (include/raytracer.h:23-735) on the MI355X path.
-// Same public data (photons, photon_depth, min_samples, max_samples, noise_thresh, ambient, _camera, width, height, p), same
-// life cycle (RayTracer(camera); setScene(octree); start(); run(w, h) on a worker thread; getImage() polled by the GUI;
-// stop()), copyable with shared scene / image exactly as gui.h:19 / viewer.h:16 need.  run() flattens + uploads when the
-// scene is not valid, emits photons on the GPU when the photon map is not valid, renders through gi_render_host and stores
-// gamma-2.2 / clamped / truncated 8-bit pixels like Image::setPixel.  Errors: the reference has no error channel (void
-// returns, stdout); here last_error() carries the C ABI's message and run() leaves the image black.
+// Same public data (photons, photon_depth, min_samples, max_samples, noise_thresh, ambient, _camera, width, height, p), same life cycle
+// (RayTracer(camera); setScene(octree); start(); run(w, h) on a worker thread while the GUI thread polls getImage() every 32 ms; stop()),
+// copyable with shared scene / photon map / image exactly as gui.h:19 / viewer.h:16 need, and the per-ray methods with the reference's
+// signatures (trace, visible, samplePhotons, radiance, tracePhotons, secondaryRay, rayType, raymarch).
+//
+// run() flattens + uploads when the scene is not valid, emits photons on the GPU when the photon map is not valid, then renders the
+// frame in stripes of `progressive_rows` rows through gi_render_host: after every stripe its pixels go through gamma 2.2 / clamp / the
+// truncating 8-bit store into the shared Image (the display frame fills top to bottom as the reference's does row by row,
+// include/raytracer.h:93-160), and `_running` is polled (include/raytracer.h:98) -- stop() ends run() within one stripe.
+// trace / visible / samplePhotons / radiance / tracePhotons run on the GPU through the C ABI (one-element batches); there is no CPU
+// renderer behind this class: without a usable HIP device run() leaves the image black and last_error() says why.
+// secondaryRay / rayType / raymarch are the kernels' per-lane functions evaluated on the host for a single vertex (detail.h) -- the
+// reference draws drand() inside them; here the draws come from the counter RNG keyed by (seed, rng_stream, rng_depth).
 #pragma once
 #include <cmath>
 #include <cstdio>
@@ -13,6 +20,9 @@
 #include <vector>
 #include "../gi_hip.h"
 #include "camera.h"
+#include "entities.h"
+#include "halton_enum.h"
+#include "halton_sampler.h"
 #include "image.h"
 #include "octree.h"
 #include "photonMap.h"
@@ -25,11 +35,12 @@ class RayTracer {
     RayTracer() = delete;
     RayTracer(const Camera& camera) : _camera(camera), _st(std::make_shared<State>()), _image(std::make_shared<Image>(0, 0)) {}
 
-    void setScene(Octree* scene)
+    void setScene(Octree* scene)   // include/raytracer.h:35-39: the photon map lives in the scene's root box
     {
         _scene = scene;
-        _st->photon_map = std::make_shared<PhotonMap>();
+        _st->photon_map = std::make_shared<PhotonMap>(scene->_root._bbox.min, scene->_root._bbox.max);
         _st->uploaded = false;
+        _st->photons_uploaded = false;
     }
 
     // RayTracer::run(w, h), include/raytracer.h:41-165
@@ -37,38 +48,74 @@ class RayTracer {
     {
         _image = std::make_shared<Image>(w, h);
         width = w; height = h;
-        if (!ensure_context() || !_scene) return;
-        if (!_scene->valid) { _scene->rebuild(); _st->uploaded = false; }
-        if (!upload_scene()) return;
-        if (!_st->photon_map->valid) {
-            tracePhotons(5, photons);
-            _st->photon_map->rebuild(_scene);
-            gi_photon_map_desc pd;
-            gih_get_photon_desc(_scene->handle(), &pd);
-            if (check(gi_upload_photons(_st->ctx, &pd)) != 0) return;
+        if (!prepare()) return;
+        const int rows = progressive_rows > 0 ? progressive_rows : h;
+        const int n_stripes = (h + rows - 1) / rows;
+        std::vector<double> lin;
+        std::vector<uint8_t> rgb;
+        _linear.assign((size_t)w * h * 3, 0.f);
+        for (int k = 0; k < n_stripes; k++) {
+            if (!_running) return;                                   // RayTracer::stop(), polled per row in the reference (include/raytracer.h:98)
+            gi_render_params rp = params(w, h);
+            rp.stripe_h = rows; rp.stripe_rank = k; rp.stripe_world = n_stripes;   // this call renders stripe k only
+            const int y0 = k * rows, nr = std::min(rows, h - y0);
+            lin.resize((size_t)nr * w * 3);
+            rgb.resize(lin.size());
+            _cancel = _running ? 0 : 1;
+            if (check(gi_render_host(_st->ctx, &rp, lin.data(), 1, nullptr, &_cancel)) != 0) return;
+            gih_to_rgb8(lin.data(), 1, (int64_t)lin.size(), rgb.data());   // gamma(color, 2.2), glm::clamp, (int)(255 c): include/raytracer.h:150-157
+            for (int y = 0; y < nr; y++)
+                for (int x = 0; x < w; x++) _image->setPixel8(x, y0 + y, &rgb[((size_t)y * w + x) * 3]);
+            for (size_t i = 0; i < lin.size(); i++) _linear[(size_t)y0 * w * 3 + i] = (float)lin[i];
+            rows_done = y0 + nr;
         }
-        gi_render_params rp = params(w, h);
-        std::vector<float> lin((size_t)w * h * 3);
-        _cancel = _running ? 0 : 1;
-        if (check(gi_render_host(_st->ctx, &rp, lin.data(), 0, nullptr, &_cancel)) != 0) return;
-        _linear = lin;
-        for (int y = 0; y < h; y++)
-            for (int x = 0; x < w; x++) {
-                const float* c = &lin[((size_t)y * w + x) * 3];
-                // gamma(color, 2.2), glm::clamp(color, 0, 1), Image::setPixel (include/raytracer.h:150-157)
-                gi::dvec3 g(std::pow((double)c[0], 1.0 / 2.2), std::pow((double)c[1], 1.0 / 2.2), std::pow((double)c[2], 1.0 / 2.2));
-                g.x = std::fmin(std::fmax(g.x, 0.0), 1.0); g.y = std::fmin(std::fmax(g.y, 0.0), 1.0); g.z = std::fmin(std::fmax(g.z, 0.0), 1.0);
-                _image->setPixel(x, y, g);
-            }
     }
 
-    // RayTracer::trace (include/raytracer.h:382-478) for a batch of rays [n][6] (origin, unit direction)
-    bool trace(int n, const double* rays, int32_t* hit, int32_t* ent, double* res8) { return ready() && check(gi_trace(_st->ctx, n, rays, hit, ent, res8)) == 0; }
-    // RayTracer::visible (include/raytracer.h:280-319): q [n][6] = shadow-ray origin, target
-    bool visible(int n, const double* q, int32_t* vis) { return ready() && check(gi_visible(_st->ctx, n, q, vis)) == 0; }
-    // RayTracer::samplePhotons(pos, dir, 32) (include/raytracer.h:532-579): q [n][6] = pos, dir
-    bool samplePhotons(int n, const double* q, double* res3) { return ready() && check(gi_gather(_st->ctx, n, q, res3, nullptr)) == 0; }
-    // RayTracer::tracePhotons (include/raytracer.h:582-715): emission on the GPU, photons appended to the map
+    // ---- per-ray methods, signatures of include/raytracer.h:167,280,382,532,582 -- each is a one-element batch on the GPU
+    bool trace(const Ray& ray, gi::dvec3& minHit, gi::dvec3& minNorm, gi::dvec2& minUV, Entity*& obj)
+    {
+        if (!ready()) return false;
+        const double r[6] = {ray.origin.x, ray.origin.y, ray.origin.z, ray.dir.x, ray.dir.y, ray.dir.z};
+        int32_t hit = 0, ent = -1;
+        double res[8];
+        if (check(gi_trace(_st->ctx, 1, r, &hit, &ent, res)) != 0 || !hit) return false;
+        minHit = gi::get3(res); minNorm = gi::get3(res + 3);
+        obj = _scene->entities()[(size_t)ent];
+        // `uv` as Entity::intersect leaves it: interpolated texCoords of a smooth triangle, asin / atan2 of a sphere, untouched for a flat triangle
+        gi::dvec3 h2(0, 0, 0), n2(0, 0, 0);
+        gi::dvec2 uv = minUV;
+        if (obj->intersect(ray, h2, n2, uv)) minUV = uv;
+        return true;
+    }
+    bool visible(const Ray& ray, double mt)
+    {
+        if (!ready()) return false;
+        const double r[6] = {ray.origin.x, ray.origin.y, ray.origin.z, ray.dir.x, ray.dir.y, ray.dir.z};
+        int32_t vis = 0;
+        return check(gi_visible_rays(_st->ctx, 1, r, &mt, &vis)) == 0 && vis != 0;
+    }
+    gi::dvec3 samplePhotons(gi::dvec3 pos, gi::dvec3 dir, int count)
+    {
+        if (count != GI_GATHER_K) { _st->err = "samplePhotons: the gather kernel selects 32 photons (the only count the reference uses)"; return gi::dvec3(0, 0, 0); }
+        if (!ready() || !photons_ready()) return gi::dvec3(0, 0, 0);
+        const double q[6] = {pos.x, pos.y, pos.z, dir.x, dir.y, dir.z};
+        double res[3] = {0, 0, 0};
+        check(gi_gather(_st->ctx, 1, q, res, nullptr));
+        return gi::get3(res);
+    }
+    // radiance(ray, 0, sampler, enumerator, sample, (1,1,1)): `sample` is the Halton index = the stream of the counter RNG
+    gi::dvec3 radiance(const Ray& ray, int depth, const Halton_sampler&, const Halton_enum&, int sample, gi::dvec3 contrib)
+    {
+        if (depth != 0 || contrib.x != 1 || contrib.y != 1 || contrib.z != 1) { _st->err = "radiance: paths start at depth 0 with contrib 1 (the recursion is a loop inside the kernel)"; return gi::dvec3(0, 0, 0); }
+        if (!ready() || !photons_ready()) return gi::dvec3(0, 0, 0);
+        const double r[6] = {ray.origin.x, ray.origin.y, ray.origin.z, ray.dir.x, ray.dir.y, ray.dir.z};
+        const uint32_t stream = (uint32_t)sample;
+        double out[3] = {0, 0, 0};
+        check(gi_radiance(_st->ctx, 1, r, &stream, seed, out));
+        return gi::get3(out);
+    }
+    // photon emission on the GPU; the stored photons are appended to the map (include/raytracer.h:582-715)
+    void tracePhotons(int maxDepth, int count, Halton_sampler&, Halton_enum&) { tracePhotons(maxDepth, count); }
     void tracePhotons(int maxDepth, int count)
     {
         if (!ready() || count <= 0 || _scene->lights.empty()) return;
@@ -76,7 +123,48 @@ class RayTracer {
         int64_t tries = 0;
         const int n = gi_emit_photons(_st->ctx, count, maxDepth, seed, out.data(), (int32_t)(out.size() / 9), &tries);
         if (n < 0) { check(n); return; }
-        _st->photon_map->push_back_flat(out.data(), n);
+        _st->photon_map->reserve(_st->photon_map->size() + n);
+        for (int i = 0; i < n; i++) _st->photon_map->push_back(new Photon(gi::get3(&out[(size_t)i * 9]), gi::get3(&out[(size_t)i * 9 + 3]), gi::get3(&out[(size_t)i * 9 + 6])));
+    }
+
+    // ---- single-vertex pieces of radiance(), include/raytracer.h:321-379,481-506,509-529: the kernels' per-lane functions on the host
+    uint32_t rng_stream = 0, rng_depth = 0;   // key of the counter RNG for the draws these three make (the reference calls drand())
+    int rayType(const Entity* entity, const Ray& ray, gi::dvec3& norm, gi::dvec2& minUV)
+    {
+        const gi::Mat m = mat_of(entity);
+        gi::dvec2 uv = minUV;
+        return gi::ray_type(m, entity->material.diffuse->getAlpha(uv), gi::to_lane_ray(ray), gi::to_v3(norm), lane_rng());
+    }
+    void secondaryRay(const Ray& ray, const Entity* current, gi::dvec3& norm, gi::dvec2& UV, double sx, double sy, gi::dvec3& refDir, gi::dvec3& f, double& roughness,
+                      gi::dvec3& contrib, double& offset)
+    {
+        const gi::Mat m = mat_of(current);
+        gi::V3 n = gi::to_v3(norm), rd, ff, cb = gi::to_v3(contrib);
+        gi::secondary_ray(gi::to_lane_ray(ray), m, gi::to_v3(current->material.diffuse->get(UV)), current->material.diffuse->getAlpha(UV), n, sx, sy, rd, ff, roughness, cb, offset, lane_rng());
+        norm = gi::from_v3(n); refDir = gi::from_v3(rd); f = gi::from_v3(ff); contrib = gi::from_v3(cb);
+    }
+    bool raymarch(const Ray& r, gi::dvec3& hit, gi::dvec3& col, double mint, double maxt)
+    {
+        if (!_scene) return false;
+        std::vector<gi::FogD> fogs;
+        std::vector<double> grid;
+        for (AtmosphereEntity* a : _scene->at)
+            if (HeightFog* hf = dynamic_cast<HeightFog*>(a)) {
+                gi::FogD fd;
+                memset(&fd, 0, sizeof fd);
+                gi::put3(fd.pos, hf->pos); gi::put3(fd.size, hf->s); gi::put3(fd.col, hf->col);
+                fd.d = hf->d; fd.sc = hf->sc;
+                gi::put3(fd.bmin, hf->bbox.min); gi::put3(fd.bmax, hf->bbox.max);
+                fd.grid_off = (int32_t)grid.size(); fd.grid_n = (int32_t)hf->noiseGrid.size();
+                grid.insert(grid.end(), hf->noiseGrid.begin(), hf->noiseGrid.end());
+                fogs.push_back(fd);
+            }
+        gi::Scene S{};
+        S.fogs = fogs.data(); S.fog_grid = grid.data(); S.n_fog = (int32_t)fogs.size();
+        gi::V3 h, c;
+        if (!gi::raymarch(S, gi::to_lane_ray(r), h, c, mint, maxt, lane_rng(), gi::P_FOG_CAMERA)) return false;
+        hit = gi::from_v3(h); col = gi::from_v3(c);
+        return true;
     }
 
     bool running() const { return _running; }
@@ -90,17 +178,20 @@ class RayTracer {
     double noise_thresh = 0.0015;
     gi::dvec3 ambient = gi::dvec3(0, 0, 0);
     uint64_t seed = 0x9E3779B97F4A7C15ull;   // counter-RNG seed (the reference seeds drand() with time(0))
+    int progressive_rows = 16;                // rows per displayed stripe of run(); 0 = the whole frame in one call
+    volatile int rows_done = 0;               // rows of the current frame already in the Image
 
     std::shared_ptr<Image> getImage() const { return _image; }
     const std::vector<float>& linear() const { return _linear; }   // float tap of the frame (pre-gamma)
     const std::string& last_error() const { return _st->err; }
+    PhotonMap* photonMap() const { return _st->photon_map.get(); }
     Camera _camera;
 
   private:
     struct State {
         gi_ctx* ctx = nullptr;
         std::shared_ptr<PhotonMap> photon_map;
-        bool uploaded = false;
+        bool uploaded = false, photons_uploaded = false;
         std::string err;
         ~State() { if (ctx) gi_destroy(ctx); }
     };
@@ -111,7 +202,35 @@ class RayTracer {
         if (rc != 0) { _st->err = "gi_create failed: no usable HIP device (this renderer has no CPU fallback)"; fprintf(stderr, "%s\n", _st->err.c_str()); return false; }
         return true;
     }
-    bool ready() { return ensure_context() && _scene && (_scene->valid || (_scene->rebuild(), true)) && upload_scene(); }
+    bool ready()
+    {
+        if (!ensure_context() || !_scene) return false;
+        if (!_scene->valid) { _scene->rebuild(); _st->uploaded = false; }
+        return upload_scene();
+    }
+    // scene tables and photon map on the device; photons are emitted once per scene (the reference keeps a valid map across frames)
+    bool prepare()
+    {
+        if (!ready()) return false;
+        return photons_ready();
+    }
+    bool photons_ready()
+    {
+        PhotonMap* pm = _st->photon_map.get();
+        if (!pm) return true;
+        if (!pm->valid) {
+            if (pm->size() == 0) tracePhotons(5, photons);          // include/raytracer.h:61-72
+            pm->rebuild();
+            _st->photons_uploaded = false;
+        }
+        if (!_st->photons_uploaded) {
+            gi_photon_map_desc pd;
+            gih_get_photon_desc(pm->handle(), &pd);
+            if (check(gi_upload_photons(_st->ctx, &pd)) != 0) return false;
+            _st->photons_uploaded = true;
+        }
+        return true;
+    }
     bool upload_scene()
     {
         if (_st->uploaded) return true;
@@ -121,12 +240,12 @@ class RayTracer {
         if (gih_get_scene_desc(_scene->handle(), &d) != 0) { _st->err = "scene octree not built"; return false; }
         if (check(gi_upload_scene(_st->ctx, &d)) != 0) return false;
         _st->uploaded = true;
-        _st->photon_map->valid = false;
+        _st->photons_uploaded = false;   // a scene upload drops the device copy of the photon map; the host map stays valid and is sent again
         return true;
     }
     int check(int rc)
     {
-        if (rc < 0) { _st->err = gi_last_error(_st->ctx); fprintf(stderr, "gi: %s\n", _st->err.c_str()); }
+        if (rc < 0 && rc != GI_E_CANCELLED) { _st->err = gi_last_error(_st->ctx); fprintf(stderr, "gi: %s\n", _st->err.c_str()); }
         return rc < 0 ? rc : 0;
     }
     gi_render_params params(int w, int h) const
@@ -142,8 +261,17 @@ class RayTracer {
         rp.seed = seed;
         return rp;
     }
+    static gi::Mat mat_of(const Entity* e)
+    {
+        gi::Mat m;
+        memset(&m, 0, sizeof m);
+        m.roughness = e->material.roughness; m.opacity = e->material.opacity; m.ior = e->material.IOR;
+        m.dtex = -1; m.etex = -1;
+        return m;
+    }
+    gi::Rng lane_rng() const { gi::Rng r = gi::rng_make(seed, rng_stream); r.depth = rng_depth; return r; }
 
-    bool _running = false;
+    volatile bool _running = false;
     volatile int _cancel = 0;
     Octree* _scene = nullptr;
     std::shared_ptr<State> _st;

@@ -144,6 +144,8 @@ int gi_get_counters(gi_ctx*, int64_t* out8);
 int gi_trace(gi_ctx*, int32_t n, const double* rays, int32_t* hit, int32_t* ent, double* res);
 /* replaces RayTracer::visible (include/raytracer.h:280-319): q [n][6] = shadow-ray origin, target point                    */
 int gi_visible(gi_ctx*, int32_t n, const double* q, int32_t* vis);
+/* the same with the reference's own arguments: rays [n][6] = shadow-ray origin + unit direction, mt [n] = squared distance to the light point */
+int gi_visible_rays(gi_ctx*, int32_t n, const double* rays, const double* mt, int32_t* vis);
 /* replaces RayTracer::samplePhotons(pos, dir, 32) (include/raytracer.h:532-579): q [n][6] = pos, dir                       */
 int gi_gather(gi_ctx*, int32_t n, const double* q, double* res3, int32_t* n_cand);
 /* replaces RayTracer::radiance(ray, 0, ...) (include/raytracer.h:167-276): rays [n][6], stream [n] = Halton sample index  */

@@ -4,8 +4,9 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
-#include "../../include/gi/raytracer.h"
-#include "../../include/gi/sceneLoader.h"
+#include <chrono>
+#include <thread>
+#include "../../include/gi/builtin_loaders.h"
 
 int main(int argc, char** argv)
 {
@@ -57,6 +58,43 @@ int main(int argc, char** argv)
         for (float v : copy.linear()) lin += v;
         printf("rendered 64x36: 8-bit sum %.6f linear mean %.9f\n", sum, lin / copy.linear().size());
         if (argc > 4) printf("saved %d %d\n", (int)img->save_ppm((std::string(argv[4]) + ".ppm").c_str()), (int)gi_save_pfm((std::string(argv[4]) + ".pfm").c_str(), copy.linear().data(), 64, 36));
+        // a second frame after a scene edit: the scene is rebuilt and uploaded again, the photon map is kept (the reference keeps a valid map
+        // across frames and never emits twice, include/raytracer.h:61-72)
+        const int photons_before = copy.photonMap()->size();
+        scene->push_back(new triangle(vertex(gi::dvec3(0, 2, 0)), vertex(gi::dvec3(.1, 2, 0)), vertex(gi::dvec3(0, 2, .1)), mat));
+        copy.run(64, 36);
+        printf("photons before %d after %d valid %d\n", photons_before, copy.photonMap()->size(), (int)scene->valid);
+        // ---- progressive display + cancellation (viewer.h:18-21,36-39, raytracer.h:93-160): the worker fills the shared image stripe by stripe,
+        // the "GUI" thread watches it and then stops it
+        RayTracer live = raytracer;
+        live.min_samples = live.max_samples = 64;
+        live.photons = 2000;
+        live.progressive_rows = 16;
+        const int W = 256, H = 256;
+        live.start();
+        std::thread worker([&]() { live.run(W, H); });
+        auto filled_rows = [&]() {   // rows of the shared image that hold a non-black pixel
+            auto im = live.getImage();
+            int n = 0;
+            if (im->width() != W) return 0;
+            for (int y = 0; y < H; y++) { bool any = false; for (int x = 0; x < W && !any; x++) { gi::dvec3 c = im->getPixel(x, y); any = c.x + c.y + c.z > 0; } n += any; }
+            return n;
+        };
+        int last = 0, polls = 0, monotone = 1, partial_seen = 0;
+        while (live.rows_done < 96 && polls < 100000) {
+            const int done = live.rows_done, f = filled_rows();
+            if (f < last) monotone = 0;
+            if (f > 0 && f < H) partial_seen = 1;
+            if (f > done + 16) monotone = 0;                       // nothing beyond the stripe in flight is ever painted
+            last = f; polls++;
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        live.stop();
+        worker.join();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const int done = live.rows_done, f = filled_rows();
+        printf("progressive: monotone %d partial_seen %d stopped at row %d of %d (filled %d) in %.1f ms running %d\n", monotone, partial_seen, done, H, f, ms, (int)live.running());
     }
     return 0;
 }

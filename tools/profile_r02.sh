@@ -8,12 +8,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--no-cpu --no-others $*"
 python3 bench.py --steps 3 --warmup 1 $ARGS > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 bench.py --steps 3 --warmup 1 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace -d $OUT/$name -o $name -- python3 bench.py --steps 1 --warmup 0 $ARGS > $OUT/$name.json 2> $OUT/$name.err; echo "$name done: $(tail -c 200 $OUT/$name.err | tr '\n' ' ')"; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py --steps 3 --warmup 1 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+pass() { name=$1; shift; timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- python3 bench.py --steps 1 --warmup 0 $ARGS > $OUT/$name.json 2> $OUT/$name.err; echo "$name done: $(tail -c 200 $OUT/$name.err | tr '\n' ' ')"; }
 pass sq_a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM
 pass sq_b SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM
 pass sq_c SQ_WAVE_CYCLES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32
-pass ta TA_BUSY TA_TOTAL_WAVEFRONTS TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ
+pass ta TA_BUSY TA_TOTAL_WAVEFRONTS
+pass tcp TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 find $OUT -name "*.csv" | head -30
