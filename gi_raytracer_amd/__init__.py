@@ -59,6 +59,7 @@ ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
     "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays",
+    "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_texture", "gih_add_material_tex", "gih_load_png", "gih_free",
     "gih_add_light", "gih_add_sphere", "gih_add_height_fog", "gih_set_ambient", "gih_get_settings", "gih_set_camera", "gih_build_octree", "gih_get_scene_desc",
@@ -101,6 +102,17 @@ def lib():
     L.gi_halton_index.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _up, _up]
     L.gi_debug_leaf_order.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _ip]
     L.gi_kat.argtypes = [vp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp]
+    L.gi_group_create.argtypes = [C.POINTER(vp), C.c_int32, _ip]
+    L.gi_group_destroy.argtypes = [vp]
+    L.gi_group_size.argtypes = [vp]
+    L.gi_group_ctx.argtypes = [vp, C.c_int32]
+    L.gi_group_ctx.restype = vp
+    L.gi_group_last_error.argtypes = [vp]
+    L.gi_group_last_error.restype = C.c_char_p
+    L.gi_group_upload_scene.argtypes = [vp, C.POINTER(SceneDesc)]
+    L.gi_group_upload_photons.argtypes = [vp, C.POINTER(PhotonMapDesc)]
+    L.gi_group_render_host.argtypes = [vp, C.POINTER(RenderParams), C.c_int32, C.c_int32, C.c_int32, vp, C.c_int, vp, vp]
+    L.gi_group_render_device.argtypes = [vp, C.POINTER(RenderParams), C.c_int32, vp, C.c_int, vp]
     L.gih_scene_create.restype = vp
     L.gih_scene_destroy.argtypes = [vp]
     L.gih_last_error.argtypes = [vp]
@@ -319,6 +331,53 @@ def save_ppm(path, lin):
     with open(path, "wb") as f:
         f.write(b"P6\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
         f.write(a.tobytes())
+
+
+class RayTracerGroup:
+    """Several devices driven from one process through the C ABI's gi_group_* entries (include/gi_hip.h): what the C++ RayTracer::run uses when
+    more than one GPU is visible.  `devices` may repeat an ordinal (several contexts on one device)."""
+
+    def __init__(self, devices):
+        self.L = lib()
+        h = C.c_void_p()
+        dv = np.ascontiguousarray(devices, np.int32)
+        rc = self.L.gi_group_create(C.byref(h), len(dv), _p(dv, _ip))
+        if rc != GI_OK:
+            raise GiError(f"gi_group_create failed ({rc}): no usable HIP device -- this path has no CPU fallback")
+        self.h = h
+        self.n = self.L.gi_group_size(h)
+
+    def __del__(self):
+        try:
+            self.L.gi_group_destroy(self.h)
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise GiError(f"{what}: {self.L.gi_group_last_error(self.h).decode()} ({rc})")
+
+    def setScene(self, scene, photons=None):
+        d = scene.desc()
+        self._check(self.L.gi_group_upload_scene(self.h, C.byref(d)), "group upload_scene")
+        if photons is not None:
+            scene.build_photon_map(photons)
+            pd = scene.photon_desc()
+            self._check(self.L.gi_group_upload_photons(self.h, C.byref(pd)), "group upload_photons")
+        return self
+
+    def run(self, params, stripe_h=16, first_stripe=0, n_stripes=None, f64=True, frame=None):
+        """gi_group_render_host: the stripes of the window into a whole-frame host buffer (rows outside the window keep what `frame` held)."""
+        w, h = params.width, params.height
+        total = (h + stripe_h - 1) // stripe_h
+        n_stripes = total if n_stripes is None else n_stripes
+        out = np.zeros((h, w, 3), np.float64 if f64 else np.float32) if frame is None else frame
+        self._check(self.L.gi_group_render_host(self.h, C.byref(params), stripe_h, first_stripe, n_stripes, out.ctypes.data_as(C.c_void_p), 1 if f64 else 0, None, None), "group render_host")
+        return out
+
+    def run_device(self, params, out_ptr, stripe_h=16, f64=False):
+        """gi_group_render_device: the whole frame gathered on the first context's device (raw device pointer)."""
+        self._check(self.L.gi_group_render_device(self.h, C.byref(params), stripe_h, C.c_void_p(out_ptr), 1 if f64 else 0, None), "group render_device")
 
 
 class RayTracer:

@@ -10,6 +10,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -897,8 +898,12 @@ struct DevBuf {
 
 }  // namespace
 
+struct StreamGrids { int init = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0; };
+
 struct gi_ctx {
     int device = 0;
+    StreamGrids grids;                // launch grids of the streaming kernels on this context's device
+    int wf_grid[6] = {0, 0, 0, 0, 0, 0};
     hipStream_t stream = nullptr;
     std::string err;
     bool have_scene = false;
@@ -1145,7 +1150,7 @@ static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     for (int k = 0; k < 4; k++) if (c->d_q[k].n < slots) HIP_TRY(c, c->d_q[k].alloc(slots));
     if (!c->d_wfcnt.p) HIP_TRY(c, c->d_wfcnt.alloc(4));
     if (!c->h_wfcnt) HIP_TRY(c, hipHostMalloc((void**)&c->h_wfcnt, 4 * sizeof(unsigned int), hipHostMallocDefault));
-    static int g_init = 0, g_gen = 0, g_trace = 0, g_shade = 0, g_gather = 0, g_accum = 0;
+    int &g_init = c->wf_grid[0], &g_gen = c->wf_grid[1], &g_trace = c->wf_grid[2], &g_shade = c->wf_grid[3], &g_gather = c->wf_grid[4], &g_accum = c->wf_grid[5];
     if (!g_trace) {
         g_init = grid_for(c, (const void*)k_wf_init); g_gen = grid_for(c, (const void*)k_wf_gen); g_trace = grid_for(c, (const void*)k_wf_trace);
         g_shade = grid_for(c, (const void*)k_wf_shade); g_gather = grid_for(c, (const void*)k_wf_gather); g_accum = grid_for(c, (const void*)k_wf_accum);
@@ -1215,11 +1220,10 @@ static void stage_end(gi_ctx* c)
     c->ev_used += 2;
 }
 
-struct StreamGrids { int init = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0; };
 static const size_t kLdsNodes = (size_t)GI_LDS_NODES * sizeof(TNode);
-static const StreamGrids& stream_grids(gi_ctx* c)
+static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process may drive several devices (gi_group_*)
 {
-    static StreamGrids g;
+    StreamGrids& g = c->grids;
     if (!g.trace) {
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
         g.shade = grid_for(c, (const void*)k_st_shade<7, 1>, kLdsNodes, GI_SHADE_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
@@ -1744,6 +1748,196 @@ int gi_halton_index(gi_ctx* c, int32_t width, int32_t height, int32_t n, const u
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out, d_o.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GI_OK;
+}
+
+// ================================================================================================= several GPUs from one process
+// The reference parallelises RayTracer::run over image rows with OpenMP (include/raytracer.h:93).  A group does the same over the GPUs of a
+// node from ONE process (the Qt application): one context and one host thread per device, the frame's stripes dealt round-robin, the scene
+// and photon tables replicated, the finished stripes gathered into one frame -- on device 0 through peer copies over xGMI
+// (gi_group_render_device) or straight into the caller's host frame (gi_group_render_host).
+struct gi_group {
+    std::vector<gi_ctx*> ctx;
+    std::vector<void*> d_part;          // per device: its stripes, compact [local_rows][w][3]
+    std::vector<size_t> part_bytes;
+    std::vector<int32_t*> d_spp;
+    std::vector<size_t> spp_bytes;
+    std::string err;
+};
+}  // extern "C" (C++ helpers below)
+#include <thread>
+namespace {
+int group_fail(gi_group* g, int code, const std::string& m) { if (g) g->err = m; return code; }
+}
+extern "C" {
+
+int gi_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int gi_group_create(gi_group** out, int32_t n_devices, const int32_t* device_ordinals)
+{
+    if (!out || n_devices < 0) return GI_E_INVALID;
+    *out = nullptr;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return GI_E_NO_DEVICE;
+    if (n_devices == 0) n_devices = visible;
+    gi_group* g = new gi_group();
+    for (int i = 0; i < n_devices; i++) {
+        gi_ctx* c = nullptr;
+        const int rc = gi_create(&c, device_ordinals ? device_ordinals[i] : i);
+        if (rc != GI_OK) { for (gi_ctx* k : g->ctx) gi_destroy(k); delete g; return rc; }
+        g->ctx.push_back(c);
+    }
+    g->d_part.assign((size_t)n_devices, nullptr); g->part_bytes.assign((size_t)n_devices, 0);
+    g->d_spp.assign((size_t)n_devices, nullptr); g->spp_bytes.assign((size_t)n_devices, 0);
+    // peer access towards device 0 for the xGMI gather (ignored where it is the same device or already enabled)
+    for (int i = 1; i < n_devices; i++) {
+        if (g->ctx[(size_t)i]->device == g->ctx[0]->device) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g->ctx[(size_t)i]->device, g->ctx[0]->device) == hipSuccess && can) {
+            (void)hipSetDevice(g->ctx[(size_t)i]->device);
+            (void)hipDeviceEnablePeerAccess(g->ctx[0]->device, 0);
+            (void)hipGetLastError();
+        }
+    }
+    *out = g;
+    return GI_OK;
+}
+
+void gi_group_destroy(gi_group* g)
+{
+    if (!g) return;
+    for (size_t i = 0; i < g->ctx.size(); i++) {
+        (void)hipSetDevice(g->ctx[i]->device);
+        if (g->d_part[i]) (void)hipFree(g->d_part[i]);
+        if (g->d_spp[i]) (void)hipFree(g->d_spp[i]);
+        gi_destroy(g->ctx[i]);
+    }
+    delete g;
+}
+
+int gi_group_size(const gi_group* g) { return g ? (int)g->ctx.size() : 0; }
+gi_ctx* gi_group_ctx(gi_group* g, int32_t i) { return (g && i >= 0 && i < (int)g->ctx.size()) ? g->ctx[(size_t)i] : nullptr; }
+const char* gi_group_last_error(const gi_group* g) { return g ? g->err.c_str() : "null group"; }
+
+int gi_group_upload_scene(gi_group* g, const gi_scene_desc* d)
+{
+    if (!g) return GI_E_INVALID;
+    for (gi_ctx* c : g->ctx) { const int rc = gi_upload_scene(c, d); if (rc) return group_fail(g, rc, gi_last_error(c)); }
+    return GI_OK;
+}
+int gi_group_upload_photons(gi_group* g, const gi_photon_map_desc* d)
+{
+    if (!g) return GI_E_INVALID;
+    for (gi_ctx* c : g->ctx) { const int rc = gi_upload_photons(c, d); if (rc) return group_fail(g, rc, gi_last_error(c)); }
+    return GI_OK;
+}
+
+// Stripes [first_stripe, first_stripe + n_stripes) of the frame (cut into stripes of stripe_h rows), stripe s on device (s - first_stripe) % n.
+// Every device renders on its own host thread; `sink(i, ctx, rp, d_part, d_spp)` then moves device i's stripes where they belong.
+static int group_render(gi_group* g, const gi_render_params* p, int32_t stripe_h, int32_t first_stripe, int32_t n_stripes, int out_is_f64, bool want_spp, volatile const int* cancel,
+                        const std::function<int(int, gi_ctx*, const gi_render_params&, int32_t /*stripe of the call or -1 = all of this device's*/, const void*, const int32_t*)>& sink)
+{
+    if (!g || !p || stripe_h <= 0 || p->width <= 0 || p->height <= 0) return GI_E_INVALID;
+    const int n = (int)g->ctx.size();
+    const int total = (p->height + stripe_h - 1) / stripe_h;
+    if (first_stripe < 0 || n_stripes < 0 || first_stripe + n_stripes > total) return group_fail(g, GI_E_INVALID, "group render: stripe window outside the frame");
+    const bool whole = first_stripe == 0 && n_stripes == total;
+    const size_t px = (size_t)(out_is_f64 ? 8 : 4) * 3;
+    std::vector<int> rcs((size_t)n, GI_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; i++)
+        th.emplace_back([&, i]() {
+            gi_ctx* c = g->ctx[(size_t)i];
+            if (hipSetDevice(c->device) != hipSuccess) { rcs[(size_t)i] = GI_E_HIP; return; }
+            gi_render_params rp = *p;
+            rp.stripe_h = stripe_h;
+            // whole frame: one call renders all stripes of this device (rank i of n); a window: one call per stripe (rank = the stripe, world = all)
+            std::vector<int32_t> calls;
+            if (whole) { if (i < total) calls.push_back(-1); }
+            else for (int32_t s = first_stripe + i; s < first_stripe + n_stripes; s += n) calls.push_back(s);
+            for (int32_t s : calls) {
+                rp.stripe_rank = s < 0 ? i : s;
+                rp.stripe_world = s < 0 ? n : total;
+                const size_t rows = (size_t)gi_local_rows(&rp);
+                if (rows == 0) continue;
+                const size_t need = rows * (size_t)p->width * px, need_spp = want_spp ? rows * (size_t)p->width * 4 : 0;
+                if (g->part_bytes[(size_t)i] < need) {
+                    if (g->d_part[(size_t)i]) (void)hipFree(g->d_part[(size_t)i]);
+                    g->d_part[(size_t)i] = nullptr; g->part_bytes[(size_t)i] = 0;
+                    if (hipMalloc(&g->d_part[(size_t)i], need) != hipSuccess) { rcs[(size_t)i] = GI_E_HIP; c->err = "group render: hipMalloc of the stripe buffer"; return; }
+                    g->part_bytes[(size_t)i] = need;
+                }
+                if (g->spp_bytes[(size_t)i] < need_spp) {
+                    if (g->d_spp[(size_t)i]) (void)hipFree(g->d_spp[(size_t)i]);
+                    g->d_spp[(size_t)i] = nullptr; g->spp_bytes[(size_t)i] = 0;
+                    if (hipMalloc((void**)&g->d_spp[(size_t)i], need_spp) != hipSuccess) { rcs[(size_t)i] = GI_E_HIP; c->err = "group render: hipMalloc of the sample-count buffer"; return; }
+                    g->spp_bytes[(size_t)i] = need_spp;
+                }
+                int rc = gi_render_device(c, &rp, g->d_part[(size_t)i], out_is_f64, want_spp ? g->d_spp[(size_t)i] : nullptr, cancel);
+                if (rc == GI_OK) rc = sink(i, c, rp, s, g->d_part[(size_t)i], want_spp ? g->d_spp[(size_t)i] : nullptr);
+                if (rc == GI_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = GI_E_HIP;
+                if (rc != GI_OK) { rcs[(size_t)i] = rc; return; }
+            }
+        });
+    for (std::thread& t : th) t.join();
+    for (int i = 0; i < n; i++)
+        if (rcs[(size_t)i] != GI_OK) return group_fail(g, rcs[(size_t)i], std::string("device ") + std::to_string(g->ctx[(size_t)i]->device) + ": " + g->ctx[(size_t)i]->err);
+    return GI_OK;
+}
+
+// rows of the frame held by a call's compact buffer, as (frame row of the block, rows, local row of the block)
+static void stripe_blocks(const gi_render_params& rp, std::vector<std::array<int, 3>>& out)
+{
+    const int total = (rp.height + rp.stripe_h - 1) / rp.stripe_h;
+    int local = 0;
+    for (int k = rp.stripe_rank; k < total; k += rp.stripe_world) {
+        const int rows = std::min(rp.stripe_h, rp.height - k * rp.stripe_h);
+        out.push_back({k * rp.stripe_h, rows, local});
+        local += rows;
+    }
+}
+
+int gi_group_render_host(gi_group* g, const gi_render_params* p, int32_t stripe_h, int32_t first_stripe, int32_t n_stripes, void* h_frame, int out_is_f64, int32_t* h_spp, volatile const int* cancel)
+{
+    if (!h_frame) return GI_E_INVALID;
+    const size_t px = (size_t)(out_is_f64 ? 8 : 4) * 3;
+    return group_render(g, p, stripe_h, first_stripe, n_stripes, out_is_f64, h_spp != nullptr, cancel,
+                        [&](int, gi_ctx* c, const gi_render_params& rp, int32_t, const void* d_part, const int32_t* d_spp) -> int {
+                            std::vector<std::array<int, 3>> blocks;
+                            stripe_blocks(rp, blocks);
+                            if (hipStreamSynchronize(c->stream) != hipSuccess) return GI_E_HIP;
+                            for (const auto& b : blocks) {     // every device writes its own rows of the caller's frame
+                                const size_t w = (size_t)rp.width;
+                                if (hipMemcpy((char*)h_frame + (size_t)b[0] * w * px, (const char*)d_part + (size_t)b[2] * w * px, (size_t)b[1] * w * px, hipMemcpyDeviceToHost) != hipSuccess) return GI_E_HIP;
+                                if (h_spp && hipMemcpy(h_spp + (size_t)b[0] * w, d_spp + (size_t)b[2] * w, (size_t)b[1] * w * 4, hipMemcpyDeviceToHost) != hipSuccess) return GI_E_HIP;
+                            }
+                            return GI_OK;
+                        });
+}
+
+int gi_group_render_device(gi_group* g, const gi_render_params* p, int32_t stripe_h, void* d_frame_on_device0, int out_is_f64, volatile const int* cancel)
+{
+    if (!g || !p || !d_frame_on_device0) return GI_E_INVALID;
+    const size_t px = (size_t)(out_is_f64 ? 8 : 4) * 3;
+    const int dev0 = g->ctx[0]->device;
+    const int total = stripe_h > 0 ? (p->height + stripe_h - 1) / stripe_h : 0;
+    return group_render(g, p, stripe_h, 0, total, out_is_f64, false, cancel,
+                        [&](int, gi_ctx* c, const gi_render_params& rp, int32_t, const void* d_part, const int32_t*) -> int {
+                            std::vector<std::array<int, 3>> blocks;
+                            stripe_blocks(rp, blocks);
+                            for (const auto& b : blocks) {     // the gather: this device's stripes into the frame on device 0, over xGMI when the devices differ
+                                const size_t w = (size_t)rp.width;
+                                void* dst = (char*)d_frame_on_device0 + (size_t)b[0] * w * px;
+                                const void* src = (const char*)d_part + (size_t)b[2] * w * px;
+                                const hipError_t e = c->device == dev0 ? hipMemcpyAsync(dst, src, (size_t)b[1] * w * px, hipMemcpyDeviceToDevice, c->stream)
+                                                                       : hipMemcpyPeerAsync(dst, dev0, src, c->device, (size_t)b[1] * w * px, c->stream);
+                                if (e != hipSuccess) return GI_E_HIP;
+                            }
+                            return GI_OK;
+                        });
 }
 
 }  // extern "C"

@@ -71,7 +71,7 @@ class Octree {
     std::vector<AtmosphereEntity*> at;
 
     // the caller keeps ownership by convention, as in the reference (raw pointers, never freed)
-    void push_back(Entity* object) { _root._entities.push_back(object); _pending.push_back(object); valid = false; }
+    void push_back(Entity* object);   // grows _root._bbox by the entity's box, as include/octree.cpp:25-38 (defined below: needs Entity)
     void push_back(Light* light) { lights.push_back(light); valid = false; }
     void push_back(AtmosphereEntity* entity) { at.push_back(entity); valid = false; }
 
@@ -201,6 +201,19 @@ inline void Octree::rebuild()
     };
     if (d.n_node > 0) fill(fill, _root, 0);
     valid = true;
+}
+
+// Octree::push_back(Entity*), include/octree.cpp:25-38: the box of the first entity initialises the root box, every entity widens it -- a
+// caller may read _root._bbox before rebuild() (RayTracer::setScene sizes the photon map with it)
+inline void Octree::push_back(Entity* object)
+{
+    const BoundingBox b = object->boundingBox();
+    if (_root._entities.empty() && _all.empty()) { _root._bbox.max = b.max; _root._bbox.min = b.min; }
+    _root._entities.push_back(object);
+    _pending.push_back(object);
+    _root._bbox.max = gi::dvec3(std::fmax(_root._bbox.max.x, b.max.x), std::fmax(_root._bbox.max.y, b.max.y), std::fmax(_root._bbox.max.z, b.max.z));
+    _root._bbox.min = gi::dvec3(std::fmin(_root._bbox.min.x, b.min.x), std::fmin(_root._bbox.min.y, b.min.y), std::fmin(_root._bbox.min.z, b.min.z));
+    valid = false;
 }
 
 inline quadMesh::quadMesh(Octree* o, gi::dvec3 v1, gi::dvec3 v2, gi::dvec3 v3, gi::dvec3 v4, const Material& m)

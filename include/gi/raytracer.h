@@ -49,27 +49,55 @@ class RayTracer {
         _image = std::make_shared<Image>(w, h);
         width = w; height = h;
         if (!prepare()) return;
+        _linear.assign((size_t)w * h * 3, 0.f);
+        if (_st->group) { run_on_group(w, h); return; }
         const int rows = progressive_rows > 0 ? progressive_rows : h;
         const int n_stripes = (h + rows - 1) / rows;
         std::vector<double> lin;
         std::vector<uint8_t> rgb;
-        _linear.assign((size_t)w * h * 3, 0.f);
         for (int k = 0; k < n_stripes; k++) {
             if (!_running) return;                                   // RayTracer::stop(), polled per row in the reference (include/raytracer.h:98)
             gi_render_params rp = params(w, h);
             rp.stripe_h = rows; rp.stripe_rank = k; rp.stripe_world = n_stripes;   // this call renders stripe k only
             const int y0 = k * rows, nr = std::min(rows, h - y0);
             lin.resize((size_t)nr * w * 3);
-            rgb.resize(lin.size());
             _cancel = _running ? 0 : 1;
             if (check(gi_render_host(_st->ctx, &rp, lin.data(), 1, nullptr, &_cancel)) != 0) return;
-            gih_to_rgb8(lin.data(), 1, (int64_t)lin.size(), rgb.data());   // gamma(color, 2.2), glm::clamp, (int)(255 c): include/raytracer.h:150-157
-            for (int y = 0; y < nr; y++)
-                for (int x = 0; x < w; x++) _image->setPixel8(x, y0 + y, &rgb[((size_t)y * w + x) * 3]);
-            for (size_t i = 0; i < lin.size(); i++) _linear[(size_t)y0 * w * 3 + i] = (float)lin[i];
-            rows_done = y0 + nr;
+            show_rows(lin.data(), rgb, y0, nr, w);
         }
     }
+
+  private:
+    // the same frame over every visible GPU (gi_group_*, include/gi_hip.h): each progressive step renders one stripe per device
+    void run_on_group(int w, int h)
+    {
+        const int rows = progressive_rows > 0 ? progressive_rows : (h + gi_group_size(_st->group) - 1) / gi_group_size(_st->group);
+        const int total = (h + rows - 1) / rows, n = gi_group_size(_st->group);
+        std::vector<double> frame((size_t)w * h * 3, 0.0);
+        std::vector<uint8_t> rgb;
+        for (int k = 0; k < total; k += n) {
+            if (!_running) return;
+            gi_render_params rp = params(w, h);
+            const int ns = std::min(n, total - k), y0 = k * rows, nr = std::min(ns * rows, h - y0);
+            _cancel = _running ? 0 : 1;
+            const int rc = gi_group_render_host(_st->group, &rp, rows, k, ns, frame.data(), 1, nullptr, &_cancel);
+            if (rc != 0) { if (rc != GI_E_CANCELLED) { _st->err = gi_group_last_error(_st->group); fprintf(stderr, "gi: %s\n", _st->err.c_str()); } return; }
+            show_rows(frame.data() + (size_t)y0 * w * 3, rgb, y0, nr, w);
+        }
+    }
+    // gamma(color, 2.2), glm::clamp, (int)(255 c) of rows [y0, y0 + nr) into the shared image: include/raytracer.h:150-157
+    void show_rows(const double* lin, std::vector<uint8_t>& rgb, int y0, int nr, int w)
+    {
+        const size_t n = (size_t)nr * w * 3;
+        rgb.resize(n);
+        gih_to_rgb8(lin, 1, (int64_t)n, rgb.data());
+        for (int y = 0; y < nr; y++)
+            for (int x = 0; x < w; x++) _image->setPixel8(x, y0 + y, &rgb[((size_t)y * w + x) * 3]);
+        for (size_t i = 0; i < n; i++) _linear[(size_t)y0 * w * 3 + i] = (float)lin[i];
+        rows_done = y0 + nr;
+    }
+
+  public:
 
     // ---- per-ray methods, signatures of include/raytracer.h:167,280,382,532,582 -- each is a one-element batch on the GPU
     bool trace(const Ray& ray, gi::dvec3& minHit, gi::dvec3& minNorm, gi::dvec2& minUV, Entity*& obj)
@@ -179,6 +207,7 @@ class RayTracer {
     gi::dvec3 ambient = gi::dvec3(0, 0, 0);
     uint64_t seed = 0x9E3779B97F4A7C15ull;   // counter-RNG seed (the reference seeds drand() with time(0))
     int progressive_rows = 16;                // rows per displayed stripe of run(); 0 = the whole frame in one call
+    std::vector<int32_t> devices;             // HIP device ordinals to render on; empty = every visible GPU (the frame's stripes are dealt round-robin)
     volatile int rows_done = 0;               // rows of the current frame already in the Image
 
     std::shared_ptr<Image> getImage() const { return _image; }
@@ -189,16 +218,23 @@ class RayTracer {
 
   private:
     struct State {
-        gi_ctx* ctx = nullptr;
+        gi_ctx* ctx = nullptr;        // the context of the per-ray methods and of photon emission; member 0 of the group when there is one
+        gi_group* group = nullptr;    // every visible GPU, when there is more than one (or `devices` says so)
         std::shared_ptr<PhotonMap> photon_map;
         bool uploaded = false, photons_uploaded = false;
         std::string err;
-        ~State() { if (ctx) gi_destroy(ctx); }
+        ~State() { if (group) gi_group_destroy(group); else if (ctx) gi_destroy(ctx); }
     };
     bool ensure_context()
     {
         if (_st->ctx) return true;
-        const int rc = gi_create(&_st->ctx, 0);
+        const int want = devices.empty() ? gi_device_count() : (int)devices.size();
+        int rc;
+        if (want > 1) {
+            rc = gi_group_create(&_st->group, (int32_t)devices.size(), devices.empty() ? nullptr : devices.data());
+            if (rc == 0) _st->ctx = gi_group_ctx(_st->group, 0);
+        } else
+            rc = gi_create(&_st->ctx, devices.empty() ? 0 : devices[0]);
         if (rc != 0) { _st->err = "gi_create failed: no usable HIP device (this renderer has no CPU fallback)"; fprintf(stderr, "%s\n", _st->err.c_str()); return false; }
         return true;
     }
@@ -226,7 +262,7 @@ class RayTracer {
         if (!_st->photons_uploaded) {
             gi_photon_map_desc pd;
             gih_get_photon_desc(pm->handle(), &pd);
-            if (check(gi_upload_photons(_st->ctx, &pd)) != 0) return false;
+            if (check(_st->group ? gi_group_upload_photons(_st->group, &pd) : gi_upload_photons(_st->ctx, &pd)) != 0) return false;
             _st->photons_uploaded = true;
         }
         return true;
@@ -238,14 +274,18 @@ class RayTracer {
         gih_set_ambient(_scene->handle(), amb);
         gi_scene_desc d;
         if (gih_get_scene_desc(_scene->handle(), &d) != 0) { _st->err = "scene octree not built"; return false; }
-        if (check(gi_upload_scene(_st->ctx, &d)) != 0) return false;
+        if (check(_st->group ? gi_group_upload_scene(_st->group, &d) : gi_upload_scene(_st->ctx, &d)) != 0) return false;
         _st->uploaded = true;
         _st->photons_uploaded = false;   // a scene upload drops the device copy of the photon map; the host map stays valid and is sent again
         return true;
     }
     int check(int rc)
     {
-        if (rc < 0 && rc != GI_E_CANCELLED) { _st->err = gi_last_error(_st->ctx); fprintf(stderr, "gi: %s\n", _st->err.c_str()); }
+        if (rc < 0 && rc != GI_E_CANCELLED) {
+            _st->err = gi_last_error(_st->ctx);
+            if (_st->err.empty() && _st->group) _st->err = gi_group_last_error(_st->group);
+            fprintf(stderr, "gi: %s\n", _st->err.c_str());
+        }
         return rc < 0 ? rc : 0;
     }
     gi_render_params params(int w, int h) const

@@ -159,6 +159,29 @@ int gi_emit_photons(gi_ctx*, int32_t count, int32_t max_depth, uint64_t seed, do
 int gi_halton_sample(gi_ctx*, int32_t n, const uint32_t* dim, const uint32_t* index, float* out);
 int gi_halton_index(gi_ctx*, int32_t width, int32_t height, int32_t n, const uint32_t* sxy /*[n][3]*/, uint32_t* out);
 
+/* Several GPUs from one process.  Replaces the OpenMP row loop of RayTracer::run (include/raytracer.h:93: `#pragma omp parallel for
+ * schedule(dynamic, 10)` over image rows) for a caller that is one process -- the Qt application: a group holds one context per device, the
+ * scene and photon tables are replicated, the frame's stripes of stripe_h rows are dealt round-robin to the devices, each rendered on its own
+ * host thread, and gathered into one frame.
+ * gi_group_create: n_devices = 0 takes every visible device; device_ordinals may repeat an ordinal (several contexts on one device: how the
+ * one-GPU tests exercise this path).  gi_group_ctx gives a member context, e.g. for gi_emit_photons on device 0.
+ * gi_group_render_host: stripes [first_stripe, first_stripe + n_stripes) of the frame, stripe s on device (s - first_stripe) % n; every device
+ * copies its rows into the caller's whole-frame host buffer h_frame [height][width][3] (float or double) and h_spp [height][width] (optional);
+ * other rows are not touched -- RayTracer::run's progressive display calls this with a window of n stripes per step.
+ * gi_group_render_device: the whole frame, gathered into d_frame_on_device0 (DEVICE pointer on the first context's device) with peer copies
+ * over xGMI.  Both return after every device has finished; errors name the device (gi_group_last_error).                              */
+typedef struct gi_group gi_group;
+int gi_device_count(void);   /* usable HIP devices (0 without a GPU or a driver) */
+int gi_group_create(gi_group** out, int32_t n_devices, const int32_t* device_ordinals);
+void gi_group_destroy(gi_group*);
+int gi_group_size(const gi_group*);
+gi_ctx* gi_group_ctx(gi_group*, int32_t i);
+const char* gi_group_last_error(const gi_group*);
+int gi_group_upload_scene(gi_group*, const gi_scene_desc*);
+int gi_group_upload_photons(gi_group*, const gi_photon_map_desc*);
+int gi_group_render_host(gi_group*, const gi_render_params*, int32_t stripe_h, int32_t first_stripe, int32_t n_stripes, void* h_frame, int out_is_f64, int32_t* h_spp, volatile const int* cancel);
+int gi_group_render_device(gi_group*, const gi_render_params*, int32_t stripe_h, void* d_frame_on_device0, int out_is_f64, volatile const int* cancel);
+
 /* Diagnostics for parity tests (not needed to render).
  * gi_debug_leaf_order: what Octree::intersectSorted(ray, 0, inf) returns (include/octree.cpp:188-211,285-313) as the device walk produces
  * it: for ray i, the non-empty leaves in visiting order as pre-order node indices in leaf_out[i*cap ..], their number in n_out[i]

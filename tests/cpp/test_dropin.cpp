@@ -45,7 +45,8 @@ int main(int argc, char** argv)
     quad->push_back(new Light(gi::dvec3(0, 5, 0), gi::dvec3(0, 0, 0), gi::dvec3(4, 4, 4), .05));
     quad->rebuild();
     printf("quad valid %d\n", (int)quad->valid);
-    if (argc > 2 && strcmp(argv[2], "gpu") == 0) {
+    if (argc > 2 && strncmp(argv[2], "gpu", 3) == 0) {
+        if (strcmp(argv[2], "gpu2") == 0) copy.devices = {0, 0, 0};   // three contexts on device 0: the several-GPU path of run() on a one-GPU box
         copy.min_samples = copy.max_samples = 4;
         copy.photons = 2000;
         copy.start();
@@ -67,6 +68,7 @@ int main(int argc, char** argv)
         // ---- progressive display + cancellation (viewer.h:18-21,36-39, raytracer.h:93-160): the worker fills the shared image stripe by stripe,
         // the "GUI" thread watches it and then stops it
         RayTracer live = raytracer;
+        live.devices = copy.devices;
         live.min_samples = live.max_samples = 64;
         live.photons = 2000;
         live.progressive_rows = 16;

@@ -42,11 +42,12 @@ def test_dropin_texture_classes_match_the_reference(golden):
 
 
 @pytest.mark.gpu
-def test_dropin_render_matches_python_path():
+@pytest.mark.parametrize("devices", ["gpu", "gpu2"])   # gpu2: RayTracer::devices = {0, 0, 0} -- run() goes through gi_group_* (one host thread and context per entry)
+def test_dropin_render_matches_python_path(devices):
     import gi_raytracer_amd as gi
     import parity_checks as pc
     build()
-    out = subprocess.run([EXE, os.path.join(ROOT, "scenes/caustics/caustics.scn"), "gpu"], check=True, capture_output=True, text=True).stdout
+    out = subprocess.run([EXE, os.path.join(ROOT, "scenes/caustics/caustics.scn"), devices], check=True, capture_output=True, text=True).stdout
     m = re.search(r"linear mean ([0-9.eE+-]+)", out)
     assert m, out
     scene = pc.load_scene("caustics")

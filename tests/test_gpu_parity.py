@@ -370,6 +370,31 @@ def test_config5_standin_fog_photons_large_tree():
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
 
 
+def test_group_of_contexts_renders_the_single_context_frame():
+    """gi_group_* (include/gi_hip.h): one process, several contexts, one host thread each, stripes dealt round-robin and gathered -- the C path a
+    C++ caller gets on a multi-GPU node.  On this one-GPU box the group holds three contexts on device 0: the frame must equal the single
+    context's bit for bit, for the whole frame (host gather and device gather) and for a window of stripes (progressive display)."""
+    import torch
+    scene = pc.load_scene("caustics")
+    rt = gi.RayTracer(0).setScene(scene)
+    ph, _ = rt.tracePhotons(3000)
+    w, h, spp = 96, 70, 4
+    full = rt.run(w, h, min_samples=spp, max_samples=spp)
+    grp = gi.RayTracerGroup([0, 0, 0]).setScene(scene, ph)
+    p = rt.params(w, h, min_samples=spp, max_samples=spp)
+    assert np.array_equal(grp.run(p, stripe_h=16), full)                    # 5 stripes (the last one 6 rows) over 3 contexts
+    assert np.array_equal(grp.run(p, stripe_h=8, f64=False), full.astype(np.float32))
+    win = grp.run(p, stripe_h=16, first_stripe=1, n_stripes=2)              # rows 16..47 only
+    assert np.array_equal(win[16:48], full[16:48]) and (win[:16] == 0).all() and (win[48:] == 0).all()
+    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
+    grp.run_device(p, buf.data_ptr(), stripe_h=16, f64=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), full)
+    # adaptive sampling through the group as well
+    pa = rt.params(w, h, min_samples=4, max_samples=16, noise_thresh=0.0015)
+    assert np.array_equal(grp.run(pa, stripe_h=16), rt.run(w, h, min_samples=4, max_samples=16, noise_thresh=0.0015))
+
+
 def test_headless_cli_writes_the_display_frame(tmp_path):
     """python -m gi_raytracer_amd scene.scn -o out.ppm: the reference's main.cpp + Viewer flow without Qt; the PPM holds the display
     transform of the frame the API returns for the same settings."""
