@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgi_raytracer_hip.so")
+LIB_PATH = os.environ.get("GI_LIB_PATH") or os.path.join(_HERE, "libgi_raytracer_hip.so")   # GI_LIB_PATH: an experimental build of the same library (tuning aid)
 DEFAULT_SEED = 0x9E3779B97F4A7C15
 
 GI_OK, GI_E_NO_DEVICE, GI_E_INVALID, GI_E_HIP, GI_E_STATE, GI_E_CANCELLED = 0, -1, -2, -3, -4, -5

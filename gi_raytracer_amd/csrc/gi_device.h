@@ -995,6 +995,9 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
 template <int FEAT, class Nodes>
 GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
+#ifdef GI_EXP_NO_SHADOW   // measurement aid (never defined in the product build): what the shade stage costs without its shadow walk
+    return true;
+#endif
     if constexpr (Nodes::kWide) {
         if constexpr (Nodes::kCoop) return visible_wide_coop<FEAT>(S, N, ray, mt, rng, light_index);
         else return visible_wide<FEAT>(S, N, ray, mt, rng, light_index);
@@ -1362,7 +1365,11 @@ GI_HD void secondary_ray(const Ray& ray, const Mat& m, V3 color, double tex_a, V
             refDir = sample_phong(reflect(ray.d, norm), (1.0 / (m.roughness)) + 1, sx, sy);
             if (dot(refDir, norm) < 0) refDir = reflect(refDir, norm);
         } else
+#ifdef GI_EXP_NO_LOBE
+            refDir = norm + v3(sx, sy, 0.1);
+#else
             refDir = hemi_cos_n(norm, (float)sx, (float)sy, 2);
+#endif
         f = 1.0 * color;
         V3 inf = color;
         contrib = contrib * inf;
@@ -1450,8 +1457,12 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
     HitRec h;
     h.pos = ld3(p.hpos); h.u = p.hu; h.v = p.hv; h.tri = p.htri; h.mf = p.pad;
+#ifdef GI_EXP_NO_HALTON   // measurement aids (never defined in the product build): the cost of single pieces of the shade stage
+    float sx = 0.3f, sy = 0.6f;
+#else
     float sx = halton_sample(S, 2 + 2 * depth, p.stream);
     float sy = halton_sample(S, 3 + 2 * depth, p.stream);
+#endif
     const Mat& m = S.mats[h.mf >> 3];
     V3 norm = shading_normal(S, h);
     V3 color = ld3(m.diffuse), emissive = ld3(m.emissive);
@@ -1486,7 +1497,11 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         double rx = rng_draw(rng, P_LIGHT_X | ((uint32_t)li << 8));
         V3 lpos = ld3(lt.pos);
         V3 so = h.pos + GI_SHADOW_BIAS * norm;
+#ifdef GI_EXP_NO_LIGHT_SAMPLE
+        V3 lightDir = (lpos + lt.rad * v3(rx, ry, 0.5)) - so;
+#else
         V3 lightDir = (lpos + lt.rad * random_unit_vec(rx, ry)) - so;
+#endif
         double maxt = len2(lightDir);
         double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
         Ray sray = make_ray(so, lightDir);

@@ -393,8 +393,25 @@ __global__ __launch_bounds__(GI_BLOCK) void k_ad_accum(Frame F, PixRec* pix, con
 // sample id = s * n_pix + i  (i = 8x8-tile-ordered pixel index): consecutive ids are neighbouring pixels of one sample index.
 struct StreamCtl {
     unsigned long long next_sample;   // next sample id to start
-    unsigned int n_new, n_cont, n_shade, n_gather, n_free, pad;
+    unsigned int n_new, n_cont, n_shade, n_gather, n_free, n_free_trace;
 };
+// Queue appends.  One atomic per wave per loop turn on ONE counter is what these kernels used to do -- and a returning atomic on a single
+// address completes every ~11 ns on this part (exp/atomic_bench.hip: 8.2 M of them take 93 ms), so the 8 M waves of a pass could not finish
+// faster than that whatever else they did.  Now every workgroup appends to a counter of its own (the same 11 ns, but only its 8-16 waves
+// contend) and writes into a segment of its own in a staging queue: the segment of workgroup b starts where the items of workgroups
+// 0 .. b-1 would end if every one of them produced an entry (seg_start: pure arithmetic on the grid-stride loop), so segments can never
+// overlap.  k_st_compact then closes the gaps -- a streaming copy of a few bytes per entry -- and leaves the total in StreamCtl.
+#define GI_CNT_STRIDE 32   // counters 128 bytes apart
+#define GI_MAX_PRODUCER_BLOCKS 2048
+enum { QC_SHADE = 0, QC_CONT = 1, QC_GATHER = 2, QC_FREE = 3, QC_KINDS = 4 };
+__device__ __forceinline__ unsigned int* blk_counter(unsigned int* bc, int kind) { return bc + ((size_t)kind * GI_MAX_PRODUCER_BLOCKS + blockIdx.x) * GI_CNT_STRIDE; }
+// items the grid-stride loop `for (i0 = b * bs; i0 < n_in; i0 += grid * bs)` gives to workgroups 0 .. b-1, every chunk counted as full
+__host__ __device__ __forceinline__ uint32_t seg_start(uint32_t b, uint32_t n_in, uint32_t grid, uint32_t bs)
+{
+    const uint32_t n_chunks = (n_in + bs - 1) / bs, full = n_chunks / grid, extra = n_chunks % grid;
+    const uint32_t lo = b < extra ? b : extra;
+    return (lo * (full + 1) + (b - lo) * full) * bs;
+}
 
 __device__ __forceinline__ void st_finish(const PathRec& p, uint32_t slot, const unsigned long long* slot_sample, unsigned long long sample0,
                                           double* lbuf, uint32_t* q_free, unsigned int* n_free, bool finished)
@@ -422,12 +439,16 @@ struct GenArgs {
 };
 template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, unsigned long long* slot_sample, unsigned long long sample0,
-                                                       GenArgs g, const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, StreamCtl* ctl,
+                                                       GenArgs g, const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, unsigned int* bc, uint32_t* segs,
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf)
 {
     const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = g.n_gen + n_a + n_b;
+    const uint32_t seg = seg_start(blockIdx.x, n_in, gridDim.x, blockDim.x);   // this workgroup's segment of the staging queues
+    if (threadIdx.x == 0) segs[blockIdx.x] = seg;
+    unsigned int* const c_shade = blk_counter(bc, QC_SHADE);
+    unsigned int* const c_free = blk_counter(bc, QC_FREE);
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = i0 + lane;
         bool hit = false, fin = false;
@@ -476,10 +497,10 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                 o[0] = L.x; o[1] = L.y; o[2] = L.z;
             }
         }
-        const uint32_t at = wave_append(&ctl->n_shade, hit);
-        if (hit) q_shade[at] = slot;
-        const uint32_t af = wave_append(&ctl->n_free, fin);
-        if (fin) q_free[af] = slot;
+        const uint32_t at = wave_append(c_shade, hit);
+        if (hit) q_shade[seg + at] = slot;
+        const uint32_t af = wave_append(c_free, fin);
+        if (fin) q_free[seg + af] = slot;
     }
 }
 
@@ -503,11 +524,17 @@ __device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& 
 
 template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
-                                                       const uint32_t* q_shade, StreamCtl* ctl, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, uint32_t* q_free, double* lbuf)
+                                                       const uint32_t* q_shade, const StreamCtl* ctl, unsigned int* bc, uint32_t* segs, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, double* g_pos,
+                                                       uint32_t* q_free, double* lbuf)
 {
     const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);
     const uint32_t n_in = ctl->n_shade;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t seg = seg_start(blockIdx.x, n_in, gridDim.x, blockDim.x);   // this workgroup's segment of the staging queues (k_st_trace)
+    if (threadIdx.x == 0) segs[blockIdx.x] = seg;
+    unsigned int* const c_cont = blk_counter(bc, QC_CONT);
+    unsigned int* const c_gather = blk_counter(bc, QC_GATHER);
+    unsigned int* const c_free = blk_counter(bc, QC_FREE);
     for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = i0 + lane;
         int fl = 0;
@@ -519,22 +546,77 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
-        const uint32_t a = wave_append(&ctl->n_cont, cont);
-        if (cont) { q_cont[a] = slot; k_cont[a] = ray_sort_key(S, pool[slot]); }
-        const uint32_t g = wave_append(&ctl->n_gather, (fl & ST_GATHER) != 0);
-        if (fl & ST_GATHER) q_gather[g] = slot;
-        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free, &ctl->n_free, valid && !cont);
+        const uint32_t a = wave_append(c_cont, cont);
+        if (cont) { q_cont[seg + a] = slot; k_cont[seg + a] = ray_sort_key(S, pool[slot]); }
+        const uint32_t g = wave_append(c_gather, (fl & ST_GATHER) != 0);
+        if (fl & ST_GATHER) {
+            // the gather query's position goes into the queue as well: the key kernel then reads 24 consecutive bytes per query
+            // instead of one scattered sector of the path pool (that read alone kept it at HBM speed)
+            q_gather[seg + g] = slot;
+            const PathRec& p = pool[slot];
+            g_pos[(size_t)(seg + g) * 3] = p.hpos[0]; g_pos[(size_t)(seg + g) * 3 + 1] = p.hpos[1]; g_pos[(size_t)(seg + g) * 3 + 2] = p.hpos[2];
+        }
+        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free + seg, c_free, valid && !cont);
+    }
+}
+
+// Closes the gaps between the workgroups' segments of up to three staging queues (one launch per producer kernel).  Stream k copies
+// width[k] 4-byte words per entry from src[k] to dst[k]; entry t of the dense queue is entry (t - prefix[r]) of segment r.  Every
+// workgroup recomputes the prefix sums of the (at most 2048) per-workgroup counts in LDS; workgroup 0 leaves the totals in StreamCtl.
+struct CompactStream { const uint32_t* src; uint32_t* dst; int width; };
+struct CompactJob {
+    CompactStream st[5];    // streams of queue A (e.g. slot + key), then queue B, queue C: n_streams[q] streams each
+    int n_streams[3];
+    int kind[3];            // QC_* counter of each queue, -1 = unused
+    int total_field[3];     // which StreamCtl field receives the total: 0 n_shade, 1 n_cont, 2 n_gather, 3 n_free (+ base), 4 n_free_trace
+    int free_base_from_trace;   // queue with total_field 3 appends behind ctl->n_free_trace
+};
+__global__ __launch_bounds__(256) void k_st_compact(CompactJob job, const unsigned int* bc, const uint32_t* segs, uint32_t n_blocks, StreamCtl* ctl)
+{
+    __shared__ uint32_t prefix[GI_MAX_PRODUCER_BLOCKS + 1];
+    int stream0 = 0;
+    for (int q = 0; q < 3; q++) {
+        if (job.kind[q] < 0) continue;
+        const unsigned int* cnt = bc + (size_t)job.kind[q] * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE;
+        __syncthreads();
+        if (threadIdx.x == 0) {                                      // serial scan of <= 2048 values: microseconds
+            uint32_t acc = 0;
+            for (uint32_t b = 0; b < n_blocks; b++) { prefix[b] = acc; acc += cnt[(size_t)b * GI_CNT_STRIDE]; }
+            prefix[n_blocks] = acc;
+        }
+        __syncthreads();
+        const uint32_t total = prefix[n_blocks];
+        const uint32_t base = (job.total_field[q] == 3 && job.free_base_from_trace) ? ctl->n_free_trace : 0u;
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+            uint32_t lo = 0, hi = n_blocks;                          // largest r with prefix[r] <= t
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
+            const size_t from = (size_t)segs[lo] + (t - prefix[lo]), to = (size_t)base + t;
+            for (int k = 0; k < job.n_streams[q]; k++) {
+                const CompactStream& cs = job.st[stream0 + k];
+                for (int w = 0; w < cs.width; w++) cs.dst[to * cs.width + w] = cs.src[from * cs.width + w];
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            switch (job.total_field[q]) {
+            case 0: ctl->n_shade = total; break;
+            case 1: ctl->n_cont = total; break;
+            case 2: ctl->n_gather = total; break;
+            case 3: ctl->n_free = base + total; break;
+            default: ctl->n_free_trace = total; break;
+            }
+        }
+        stream0 += job.n_streams[q];
     }
 }
 
 // gather queries are sorted by the photon-map leaf that contains them: queries of one leaf share their candidate photons, so
 // the lanes of a wave read the same photons (one cache line instead of 64) and run loops of equal length
-__global__ __launch_bounds__(GI_BLOCK) void k_st_gkeys(Scene S, const PathRec* pool, const uint32_t* q_gather, const StreamCtl* ctl, uint32_t* keys, uint32_t* vals)
+__global__ __launch_bounds__(GI_BLOCK) void k_st_gkeys(Scene S, const double* g_pos, const uint32_t* q_gather, const StreamCtl* ctl, uint32_t* keys, uint32_t* vals)
 {
     const uint32_t n_in = ctl->n_gather;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
         const uint32_t slot = q_gather[i];
-        const int32_t leaf = gather_find_leaf(S, ld3(pool[slot].hpos));
+        const int32_t leaf = gather_find_leaf(S, ld3(g_pos + (size_t)i * 3));
         keys[i] = leaf < 0 ? (uint32_t)S.n_pnode : (uint32_t)leaf;
         vals[i] = slot;
     }
@@ -898,7 +980,7 @@ struct DevBuf {
 
 }  // namespace
 
-struct StreamGrids { int init = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0; };
+struct StreamGrids { int init = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0, compact = 0; };
 
 struct gi_ctx {
     int device = 0;
@@ -943,6 +1025,11 @@ struct gi_ctx {
     DevBuf<uint32_t> d_qs[6];         // streaming queues: new, cont ping, cont pong, shade, gather, free ping/pong share [5] + d_q
     DevBuf<StreamCtl> d_ctl;
     DevBuf<uint32_t> d_gk[2], d_gv[2];   // gather sort: keys / values, in / out
+    DevBuf<double> d_gpos;               // positions of the gather queries, dense in queue order (k_st_shade -> k_st_gkeys)
+    DevBuf<uint32_t> d_stage[4];         // staging queues the producers append to, one segment per workgroup (k_st_compact closes the gaps)
+    DevBuf<double> d_stage_pos;
+    DevBuf<unsigned int> d_blkcnt;       // per-workgroup append counters [QC_KINDS][GI_MAX_PRODUCER_BLOCKS], 128 bytes apart
+    DevBuf<uint32_t> d_segs;             // segment start of every producer workgroup
     DevBuf<uint32_t> d_ck[2], d_cv;      // continuing-ray sort: keys in / out, unsorted slots
     DevBuf<unsigned char> d_sort_tmp;
     StreamCtl* h_ctl = nullptr;
@@ -1227,7 +1314,7 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
     if (!g.trace) {
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
         g.shade = grid_for(c, (const void*)k_st_shade<7, 1>, kLdsNodes, GI_SHADE_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
-        g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
+        g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
     return g;
 }
@@ -1240,6 +1327,12 @@ static int stream_alloc(gi_ctx* c, uint32_t P)
     if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
     for (int k = 0; k < 2; k++) { if (c->d_gk[k].n < P) HIP_TRY(c, c->d_gk[k].alloc(P)); if (c->d_gv[k].n < P) HIP_TRY(c, c->d_gv[k].alloc(P)); }
     for (int k = 0; k < 2; k++) if (c->d_ck[k].n < P) HIP_TRY(c, c->d_ck[k].alloc(P));
+    if (c->d_gpos.n < (size_t)P * 3) HIP_TRY(c, c->d_gpos.alloc((size_t)P * 3));
+    const size_t PS = (size_t)P + 4096;   // segments are laid out as if every chunk of a producer's loop were full: up to one chunk of slack
+    for (int k = 0; k < 4; k++) if (c->d_stage[k].n < PS) HIP_TRY(c, c->d_stage[k].alloc(PS));
+    if (c->d_stage_pos.n < PS * 3) HIP_TRY(c, c->d_stage_pos.alloc(PS * 3));
+    if (!c->d_blkcnt.p) HIP_TRY(c, c->d_blkcnt.alloc((size_t)QC_KINDS * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE));
+    if (!c->d_segs.p) HIP_TRY(c, c->d_segs.alloc(GI_MAX_PRODUCER_BLOCKS));
     if (c->d_cv.n < P) HIP_TRY(c, c->d_cv.alloc(P));
     {
         size_t need = 0;
@@ -1304,18 +1397,46 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         HIP_TRY(c, hipMemsetAsync(ctl, 0, sizeof(StreamCtl), st));
         uint32_t* qfree_out = q_free[ping];
         const bool sph = c->S.has_spheres != 0, fog = c->S.n_fog > 0, tex = c->S.n_tex > 0;
-        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, ctl,
-                           q_shade, qfree_out, lbuf); stage_end(c);
-        stage_begin(c, STG_SHADE); hipLaunchKernelGGL(tex ? (wide ? k_st_shade<7, 1> : k_st_shade<7, 0>) : wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, c->d_cv.p, c->d_ck[0].p, q_gather,
-                           qfree_out, lbuf); stage_end(c);
-        launches += 2;
+        if (G.trace > GI_MAX_PRODUCER_BLOCKS || G.shade > GI_MAX_PRODUCER_BLOCKS) return fail(c, GI_E_STATE, "render: more producer workgroups than per-workgroup counters");
+        unsigned int* bc = c->d_blkcnt.p;
+        const size_t bc_bytes = (size_t)QC_KINDS * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE * sizeof(unsigned int);
+        // trace: hits -> staging 0, finished paths -> staging 1; compacted into the shade queue and the head of the free list
+        HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
+        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, bc, c->d_segs.p,
+                           c->d_stage[0].p, c->d_stage[1].p, lbuf); stage_end(c);
+        {
+            CompactJob job;
+            memset(&job, 0, sizeof job);
+            job.st[0] = {c->d_stage[0].p, q_shade, 1}; job.n_streams[0] = 1; job.kind[0] = QC_SHADE; job.total_field[0] = 0;
+            job.st[1] = {c->d_stage[1].p, qfree_out, 1}; job.n_streams[1] = 1; job.kind[1] = QC_FREE; job.total_field[1] = 4;
+            job.kind[2] = -1;
+            stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, job, bc, c->d_segs.p, (uint32_t)G.trace, ctl); stage_end(c);
+        }
+        // shade: continuing rays (slot + key) -> staging 0 / 1, gather queries (slot + position) -> staging 2 / pos, finished paths -> staging 3
+        HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
+        stage_begin(c, STG_SHADE); hipLaunchKernelGGL(tex ? (wide ? k_st_shade<7, 1> : k_st_shade<7, 0>) : wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, bc, c->d_segs.p,
+                           c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf); stage_end(c);
+        {
+            CompactJob job;
+            memset(&job, 0, sizeof job);
+            // streams in queue order: [0] continuing slot, [1] its coherence key, [2] gather slot, [3] gather position (3 doubles = 6 words), [4] freed slot
+            job.st[0] = {c->d_stage[0].p, c->d_cv.p, 1}; job.st[1] = {c->d_stage[1].p, c->d_ck[0].p, 1};
+            job.n_streams[0] = 2; job.kind[0] = QC_CONT; job.total_field[0] = 1;
+            job.st[2] = {c->d_stage[2].p, q_gather, 1};
+            job.st[3] = {reinterpret_cast<const uint32_t*>(c->d_stage_pos.p), reinterpret_cast<uint32_t*>(c->d_gpos.p), 6};
+            job.n_streams[1] = 2; job.kind[1] = QC_GATHER; job.total_field[1] = 2;
+            job.st[4] = {c->d_stage[3].p, qfree_out, 1};
+            job.n_streams[2] = 1; job.kind[2] = QC_FREE; job.total_field[2] = 3; job.free_base_from_trace = 1;
+            stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, job, bc, c->d_segs.p, (uint32_t)G.shade, ctl); stage_end(c);
+        }
+        launches += 4;
         HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         const uint32_t n_gather = c->h_ctl->n_gather;
         if (c->S.n_pnode > 0 && n_gather > 0) {
             int bits = 1;
             while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
-            stage_begin(c, STG_SORT); hipLaunchKernelGGL(k_st_gkeys, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p); stage_end(c);
+            stage_begin(c, STG_SORT); hipLaunchKernelGGL(k_st_gkeys, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, c->d_gpos.p, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p); stage_end(c);
             size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
             HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
@@ -1350,7 +1471,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = c->d_pool.n * sizeof(PathRec) + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7;   // ours, re-usable
-            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24;   // record, sample id, 13 queue / key words, sort scratch
+            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 24 + 40;   // record, sample id, 13 queue / key words, sort scratch, gather position, staging queues
             const size_t lbuf = (size_t)n_pix * (size_t)std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)) * 24;
             const size_t avail = (size_t)((double)(free_b + held) * 0.80);
             if (avail > lbuf) slots_budget = std::min(slots_budget, (avail - lbuf) / per_slot);

@@ -15,6 +15,7 @@ int main(int argc, char** argv)
     RayTracer raytracer(camera);                                   // main.cpp:30
     Octree* scene = new Octree();                                  // main.cpp:34
     loadScene(scene, raytracer, argv[1]);                          // main.cpp:36-39
+    if (argc > 2 && strncmp(argv[2], "gpu", 3) == 0) raytracer.ambient = gi::dvec3(0.05, 0.06, 0.07);   // a sky that is not black: every rendered row shows in the image
     raytracer.setScene(scene);                                     // main.cpp:41
     RayTracer copy = raytracer;                                    // gui.h:19 / viewer.h:16 pass it by value
     scene->rebuild();
@@ -72,7 +73,7 @@ int main(int argc, char** argv)
         live.min_samples = live.max_samples = 64;
         live.photons = 2000;
         live.progressive_rows = 16;
-        const int W = 256, H = 256;
+        const int W = 512, H = 512;
         live.start();
         std::thread worker([&]() { live.run(W, H); });
         auto filled_rows = [&]() {   // rows of the shared image that hold a non-black pixel
@@ -96,6 +97,7 @@ int main(int argc, char** argv)
         worker.join();
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         const int done = live.rows_done, f = filled_rows();
+        if (f > 0 && f < H) partial_seen = 1;                      // the frame the GUI is left with is the part rendered so far
         printf("progressive: monotone %d partial_seen %d stopped at row %d of %d (filled %d) in %.1f ms running %d\n", monotone, partial_seen, done, H, f, ms, (int)live.running());
     }
     return 0;

@@ -50,8 +50,9 @@ def test_dropin_render_matches_python_path(devices):
     out = subprocess.run([EXE, os.path.join(ROOT, "scenes/caustics/caustics.scn"), devices], check=True, capture_output=True, text=True).stdout
     m = re.search(r"linear mean ([0-9.eE+-]+)", out)
     assert m, out
-    scene = pc.load_scene("caustics")
-    rt = gi.RayTracer(0).setScene(scene)
+    scene = gi.Scene.load(os.path.join(ROOT, "scenes/caustics/caustics.scn"))
+    scene.set_ambient((0.05, 0.06, 0.07))          # as the C++ program sets RayTracer::ambient
+    rt = gi.RayTracer(0).setScene(scene.rebuild())
     rt.tracePhotons(2000)
     img = rt.run(64, 36, f64=False, min_samples=4, max_samples=4)
     assert abs(float(m.group(1)) - float(img.astype(np.float64).mean())) < 1e-9
@@ -59,8 +60,8 @@ def test_dropin_render_matches_python_path(devices):
     m = re.search(r"photons before (\d+) after (\d+) valid 1", out)
     assert m and m.group(1) == m.group(2) and int(m.group(1)) > 0, out
     # progressive display: the shared image fills top to bottom, stripe by stripe; stop() ends run() within one stripe
-    m = re.search(r"progressive: monotone (\d) partial_seen (\d) stopped at row (\d+) of 256 \(filled (\d+)\) in ([0-9.]+) ms running 0", out)
+    m = re.search(r"progressive: monotone (\d) partial_seen (\d) stopped at row (\d+) of 512 \(filled (\d+)\) in ([0-9.]+) ms running 0", out)
     assert m, out
     assert m.group(1) == "1" and m.group(2) == "1"
-    assert 96 <= int(m.group(3)) < 256 and int(m.group(4)) <= int(m.group(3))          # it did stop before the frame was complete
+    assert 96 <= int(m.group(3)) < 512 and int(m.group(4)) <= int(m.group(3))          # it did stop before the frame was complete
     assert float(m.group(5)) < 2000.0                                                  # within one 16-row stripe (a few ms of GPU work; generous bound)

@@ -374,7 +374,6 @@ def test_group_of_contexts_renders_the_single_context_frame():
     """gi_group_* (include/gi_hip.h): one process, several contexts, one host thread each, stripes dealt round-robin and gathered -- the C path a
     C++ caller gets on a multi-GPU node.  On this one-GPU box the group holds three contexts on device 0: the frame must equal the single
     context's bit for bit, for the whole frame (host gather and device gather) and for a window of stripes (progressive display)."""
-    import torch
     scene = pc.load_scene("caustics")
     rt = gi.RayTracer(0).setScene(scene)
     ph, _ = rt.tracePhotons(3000)
@@ -386,10 +385,19 @@ def test_group_of_contexts_renders_the_single_context_frame():
     assert np.array_equal(grp.run(p, stripe_h=8, f64=False), full.astype(np.float32))
     win = grp.run(p, stripe_h=16, first_stripe=1, n_stripes=2)              # rows 16..47 only
     assert np.array_equal(win[16:48], full[16:48]) and (win[:16] == 0).all() and (win[48:] == 0).all()
-    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda:0")
-    grp.run_device(p, buf.data_ptr(), stripe_h=16, f64=True)
-    torch.cuda.synchronize()
-    assert np.array_equal(buf.cpu().numpy(), full)
+    # the device gather: a frame buffer on device 0 from the HIP runtime the library itself uses (no second runtime in this process)
+    import ctypes
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+    d_buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_buf), ctypes.c_size_t(full.nbytes)) == 0
+    try:
+        assert hip.hipMemset(d_buf, 0, ctypes.c_size_t(full.nbytes)) == 0
+        grp.run_device(p, d_buf.value, stripe_h=16, f64=True)
+        got = np.zeros_like(full)
+        assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), d_buf, ctypes.c_size_t(full.nbytes), 2) == 0   # hipMemcpyDeviceToHost
+    finally:
+        hip.hipFree(d_buf)
+    assert np.array_equal(got, full)
     # adaptive sampling through the group as well
     pa = rt.params(w, h, min_samples=4, max_samples=16, noise_thresh=0.0015)
     assert np.array_equal(grp.run(pa, stripe_h=16), rt.run(w, h, min_samples=4, max_samples=16, noise_thresh=0.0015))
