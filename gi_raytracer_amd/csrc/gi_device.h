@@ -732,12 +732,16 @@ GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rn
             for (int32_t j = 0; j < cnt_u; j++) test(leaf_tri_scalar(S.leaf_tris + first_u + j));
         } else
 #endif
+#ifdef GI_EXP_ONE_TRI
+        for (int32_t j = 0; j < cnt; j++) test(S.leaf_tris[first + j]);
+#else
         for (int32_t j = 0; j < cnt; j += 2) {
             const LeafTri g0 = S.leaf_tris[first + j];
             const LeafTri g1 = S.leaf_tris[first + (j + 1 < cnt ? j + 1 : j)];
             test(g0);
             if (j + 1 < cnt) test(g1);
         }
+#endif
         if (term) break;
     }
     return intersected;
@@ -1446,9 +1450,28 @@ GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     N.g = S.tnodes;
     return S.n_tex > 0 ? stage_trace_nodes<7>(S, N, p, seed, c) : stage_trace_nodes<3>(S, N, p, seed, c);
 }
+// coherence key of a continuing ray: direction octant (selects the order the children are walked in), Morton code of the origin inside the
+// root box, coarse direction -- rays that are neighbours in this order walk the same nodes for about the same number of steps
+GI_HD uint32_t coherence_key(const Scene& S, V3 o, V3 d)
+{
+    uint32_t m = 0;
+    uint32_t q[3];
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    for (int k = 0; k < 3; k++) {
+        double f = (oo[k] - S.root_bmin[k]) / (S.root_bmax[k] - S.root_bmin[k]);
+        f = f < 0.0 ? 0.0 : (f > 0.999 ? 0.999 : f);
+        q[k] = (uint32_t)(f * 64.0);
+    }
+    for (int b = 5; b >= 0; b--) m = (m << 3) | (((q[0] >> b) & 1u) << 2) | (((q[1] >> b) & 1u) << 1) | ((q[2] >> b) & 1u);
+    const uint32_t oct = (dd[0] < 0.0 ? 1u : 0u) | (dd[2] < 0.0 ? 2u : 0u) | (dd[1] < 0.0 ? 4u : 0u);
+    uint32_t db = 0;
+    for (int k = 0; k < 3; k++) { double a = fabs(dd[k]); db = (db << 2) | (uint32_t)(a >= 0.999 ? 3.0 : a * 4.0); }
+    return (oct << 24) | (m << 6) | db;
+}
+struct ShadeOut { uint32_t key; V3 gpos; };   // by-products of the shade stage for the queues: sort key of the next ray, position of the gather query
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
 template <int FEAT, class Nodes>
-GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c)
+GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr)
 {
     Rng rng = rng_make(seed, p.stream);
     const int depth = p.depth;
@@ -1464,7 +1487,11 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     float sy = halton_sample(S, 3 + 2 * depth, p.stream);
 #endif
     const Mat& m = S.mats[h.mf >> 3];
+#if defined(GI_EXP_SHADE) && GI_EXP_SHADE >= 2
+    V3 norm = v3(0, 1, 0);
+#else
     V3 norm = shading_normal(S, h);
+#endif
     V3 color = ld3(m.diffuse), emissive = ld3(m.emissive);
     double tex_a = 1;
     if (FEAT & GI_FEAT_TEX) {   // diffuse->get(minUV), emissive->get(minUV), diffuse->getAlpha(minUV): include/raytracer.h:200,269,486
@@ -1515,12 +1542,18 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
             i = ld3(lt.col) * l * hfrac;
         }
     }
+#if !defined(GI_EXP_SHADE) || GI_EXP_SHADE < 3
     p.contrib[0] = contrib.x; p.contrib[1] = contrib.y; p.contrib[2] = contrib.z;
+#endif
     V3 T = depth == 0 ? v3(1, 1, 1) : ld3(p.T), L = depth == 0 ? v3(0, 0, 0) : ld3(p.L);
     double q = comp_max(contrib);
     if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
         f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
         L = L + T * (color * i + emissive);
+#if defined(GI_EXP_SHADE) && GI_EXP_SHADE >= 3
+        if (L.x == 1.2345e300) p.L[0] = L.x + refDir.x + contrib.x + f.x;   // keeps the arithmetic alive, stores nothing
+        return ST_CONTINUE | ST_GATHER;
+#endif
         p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
         int flags = 0;
         if (depth <= 10 && S.n_pnode > 0) {   // caustic = depth <= 10 ? samplePhotons(minHit, refDir, 32) : 0, include/raytracer.h:258
@@ -1535,6 +1568,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         p.o[0] = next.o.x; p.o[1] = next.o.y; p.o[2] = next.o.z;
         p.d[0] = next.d.x; p.d[1] = next.d.y; p.d[2] = next.d.z;
         p.depth = depth + 1;
+        if (so) { so->key = coherence_key(S, next.o, next.d); so->gpos = h.pos; }
         if (p.depth <= GI_MAX_DEPTH) flags |= ST_CONTINUE;   // radiance() returns 0 past MAX_DEPTH
         return flags;
     }

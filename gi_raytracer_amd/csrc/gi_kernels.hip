@@ -26,6 +26,9 @@
 using namespace gi;
 
 #define GI_BLOCK 256
+#ifndef GI_EXP_SHADE
+#define GI_EXP_SHADE 0
+#endif
 
 // ================================================================================================= kernels
 template <bool COUNT>
@@ -504,24 +507,6 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
     }
 }
 
-// coherence key of a continuing ray: direction octant (selects the node array), Morton code of the origin inside the root box,
-// coarse direction -- rays that are neighbours in this order walk the same nodes for about the same number of steps
-__device__ __forceinline__ uint32_t ray_sort_key(const Scene& S, const PathRec& p)
-{
-    uint32_t m = 0;
-    uint32_t q[3];
-    for (int k = 0; k < 3; k++) {
-        double f = (p.o[k] - S.root_bmin[k]) / (S.root_bmax[k] - S.root_bmin[k]);
-        f = f < 0.0 ? 0.0 : (f > 0.999 ? 0.999 : f);
-        q[k] = (uint32_t)(f * 64.0);
-    }
-    for (int b = 5; b >= 0; b--) m = (m << 3) | (((q[0] >> b) & 1u) << 2) | (((q[1] >> b) & 1u) << 1) | ((q[2] >> b) & 1u);
-    const uint32_t oct = (p.d[0] < 0.0 ? 1u : 0u) | (p.d[2] < 0.0 ? 2u : 0u) | (p.d[1] < 0.0 ? 4u : 0u);
-    uint32_t db = 0;
-    for (int k = 0; k < 3; k++) { double a = fabs(p.d[k]); db = (db << 2) | (uint32_t)(a >= 0.999 ? 3.0 : a * 4.0); }
-    return (oct << 24) | (m << 6) | db;
-}
-
 template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, const StreamCtl* ctl, unsigned int* bc, uint32_t* segs, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, double* g_pos,
@@ -540,21 +525,38 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
         int fl = 0;
         bool valid = i < n_in;
         uint32_t slot = 0;
+        ShadeOut so;
+        so.key = 0; so.gpos = v3(0, 0, 0);
         if (valid) {
             slot = q_shade[i];
-            fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr);
+#if GI_EXP_SHADE >= 5   // measurement aids (never defined in the product build): bisecting the cost of the shade stage
+            fl = ST_CONTINUE | ST_GATHER;
+#else
+            fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr, &so);
+#endif
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
+#if GI_EXP_SHADE >= 4
+        if (cont && slot == 0xfffffff0u) q_cont[0] = slot;
+        continue;
+#endif
         const uint32_t a = wave_append(c_cont, cont);
-        if (cont) { q_cont[seg + a] = slot; k_cont[seg + a] = ray_sort_key(S, pool[slot]); }
+#if GI_EXP_SHADE >= 1
+        if (cont) { q_cont[seg + a] = slot; k_cont[seg + a] = slot >> 8; }
+#else
+        if (cont) { q_cont[seg + a] = slot; k_cont[seg + a] = so.key; }   // the key of the next ray, from the registers that just held it
+#endif
         const uint32_t g = wave_append(c_gather, (fl & ST_GATHER) != 0);
         if (fl & ST_GATHER) {
             // the gather query's position goes into the queue as well: the key kernel then reads 24 consecutive bytes per query
             // instead of one scattered sector of the path pool (that read alone kept it at HBM speed)
             q_gather[seg + g] = slot;
-            const PathRec& p = pool[slot];
-            g_pos[(size_t)(seg + g) * 3] = p.hpos[0]; g_pos[(size_t)(seg + g) * 3 + 1] = p.hpos[1]; g_pos[(size_t)(seg + g) * 3 + 2] = p.hpos[2];
+#if GI_EXP_SHADE >= 1
+            g_pos[(size_t)(seg + g) * 3] = 0.1; g_pos[(size_t)(seg + g) * 3 + 1] = 0.1; g_pos[(size_t)(seg + g) * 3 + 2] = 0.1;
+#else
+            g_pos[(size_t)(seg + g) * 3] = so.gpos.x; g_pos[(size_t)(seg + g) * 3 + 1] = so.gpos.y; g_pos[(size_t)(seg + g) * 3 + 2] = so.gpos.z;
+#endif
         }
         st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free + seg, c_free, valid && !cont);
     }
@@ -563,6 +565,8 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
 // Closes the gaps between the workgroups' segments of up to three staging queues (one launch per producer kernel).  Stream k copies
 // width[k] 4-byte words per entry from src[k] to dst[k]; entry t of the dense queue is entry (t - prefix[r]) of segment r.  Every
 // workgroup recomputes the prefix sums of the (at most 2048) per-workgroup counts in LDS; workgroup 0 leaves the totals in StreamCtl.
+// The queue of gather queries is not copied but turned into the input of its sort: (key = photon-map leaf that contains the query's
+// position, value = slot) -- PhotonMap::Node::getBounds' descent (gather_find_leaf) runs here, on positions read in queue order.
 struct CompactStream { const uint32_t* src; uint32_t* dst; int width; };
 struct CompactJob {
     CompactStream st[5];    // streams of queue A (e.g. slot + key), then queue B, queue C: n_streams[q] streams each
@@ -570,19 +574,30 @@ struct CompactJob {
     int kind[3];            // QC_* counter of each queue, -1 = unused
     int total_field[3];     // which StreamCtl field receives the total: 0 n_shade, 1 n_cont, 2 n_gather, 3 n_free (+ base), 4 n_free_trace
     int free_base_from_trace;   // queue with total_field 3 appends behind ctl->n_free_trace
+    int gather_queue;       // index of the queue whose streams are (slot, position): dst of stream 0 = values, dst of stream 1 = keys; -1 = none
 };
-__global__ __launch_bounds__(256) void k_st_compact(CompactJob job, const unsigned int* bc, const uint32_t* segs, uint32_t n_blocks, StreamCtl* ctl)
+__global__ __launch_bounds__(256) void k_st_compact(Scene S, CompactJob job, const unsigned int* bc, const uint32_t* segs, uint32_t n_blocks, StreamCtl* ctl)
 {
     __shared__ uint32_t prefix[GI_MAX_PRODUCER_BLOCKS + 1];
+    __shared__ uint32_t part[256];
     int stream0 = 0;
     for (int q = 0; q < 3; q++) {
         if (job.kind[q] < 0) continue;
         const unsigned int* cnt = bc + (size_t)job.kind[q] * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE;
+        // exclusive prefix sums of the per-workgroup counts: thread t owns counts [t * per, t * per + per)
+        const uint32_t per = (n_blocks + 255u) / 256u;
         __syncthreads();
-        if (threadIdx.x == 0) {                                      // serial scan of <= 2048 values: microseconds
+        {
             uint32_t acc = 0;
-            for (uint32_t b = 0; b < n_blocks; b++) { prefix[b] = acc; acc += cnt[(size_t)b * GI_CNT_STRIDE]; }
-            prefix[n_blocks] = acc;
+            for (uint32_t k = 0; k < per; k++) { const uint32_t b = threadIdx.x * per + k; if (b < n_blocks) acc += cnt[(size_t)b * GI_CNT_STRIDE]; }
+            part[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t acc = 0; for (int t = 0; t < 256; t++) { const uint32_t v = part[t]; part[t] = acc; acc += v; } prefix[n_blocks] = acc; }
+        __syncthreads();
+        {
+            uint32_t acc = part[threadIdx.x];
+            for (uint32_t k = 0; k < per; k++) { const uint32_t b = threadIdx.x * per + k; if (b < n_blocks) { prefix[b] = acc; acc += cnt[(size_t)b * GI_CNT_STRIDE]; } }
         }
         __syncthreads();
         const uint32_t total = prefix[n_blocks];
@@ -591,6 +606,14 @@ __global__ __launch_bounds__(256) void k_st_compact(CompactJob job, const unsign
             uint32_t lo = 0, hi = n_blocks;                          // largest r with prefix[r] <= t
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (prefix[mid] <= t) lo = mid; else hi = mid; }
             const size_t from = (size_t)segs[lo] + (t - prefix[lo]), to = (size_t)base + t;
+            if (q == job.gather_queue) {
+                const CompactStream& sl = job.st[stream0];
+                const double* pos = reinterpret_cast<const double*>(job.st[stream0 + 1].src) + from * 3;
+                const int32_t leaf = gather_find_leaf(S, v3(pos[0], pos[1], pos[2]));
+                sl.dst[to] = sl.src[from];
+                job.st[stream0 + 1].dst[to] = leaf < 0 ? (uint32_t)S.n_pnode : (uint32_t)leaf;
+                continue;
+            }
             for (int k = 0; k < job.n_streams[q]; k++) {
                 const CompactStream& cs = job.st[stream0 + k];
                 for (int w = 0; w < cs.width; w++) cs.dst[to * cs.width + w] = cs.src[from * cs.width + w];
@@ -609,18 +632,8 @@ __global__ __launch_bounds__(256) void k_st_compact(CompactJob job, const unsign
     }
 }
 
-// gather queries are sorted by the photon-map leaf that contains them: queries of one leaf share their candidate photons, so
-// the lanes of a wave read the same photons (one cache line instead of 64) and run loops of equal length
-__global__ __launch_bounds__(GI_BLOCK) void k_st_gkeys(Scene S, const double* g_pos, const uint32_t* q_gather, const StreamCtl* ctl, uint32_t* keys, uint32_t* vals)
-{
-    const uint32_t n_in = ctl->n_gather;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_in; i += gridDim.x * blockDim.x) {
-        const uint32_t slot = q_gather[i];
-        const int32_t leaf = gather_find_leaf(S, ld3(g_pos + (size_t)i * 3));
-        keys[i] = leaf < 0 ? (uint32_t)S.n_pnode : (uint32_t)leaf;
-        vals[i] = slot;
-    }
-}
+// Gather queries are sorted by the photon-map leaf that contains them (keys from k_st_compact): queries of one leaf share their candidate
+// photons, so the lanes of a wave read the same photons and run loops of equal length.
 // Queries arrive sorted by leaf, and a leaf typically serves thousands of queries per pass, so most waves hold 64 queries of ONE
 // leaf: such a wave copies the leaf's candidate photons into LDS once (64 at a time, one photon per lane, coalesced) and every lane
 // scans them from there -- a broadcast LDS read per candidate instead of an L2 round trip per lane.  Waves that straddle a leaf
@@ -1025,7 +1038,6 @@ struct gi_ctx {
     DevBuf<uint32_t> d_qs[6];         // streaming queues: new, cont ping, cont pong, shade, gather, free ping/pong share [5] + d_q
     DevBuf<StreamCtl> d_ctl;
     DevBuf<uint32_t> d_gk[2], d_gv[2];   // gather sort: keys / values, in / out
-    DevBuf<double> d_gpos;               // positions of the gather queries, dense in queue order (k_st_shade -> k_st_gkeys)
     DevBuf<uint32_t> d_stage[4];         // staging queues the producers append to, one segment per workgroup (k_st_compact closes the gaps)
     DevBuf<double> d_stage_pos;
     DevBuf<unsigned int> d_blkcnt;       // per-workgroup append counters [QC_KINDS][GI_MAX_PRODUCER_BLOCKS], 128 bytes apart
@@ -1327,7 +1339,6 @@ static int stream_alloc(gi_ctx* c, uint32_t P)
     if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
     for (int k = 0; k < 2; k++) { if (c->d_gk[k].n < P) HIP_TRY(c, c->d_gk[k].alloc(P)); if (c->d_gv[k].n < P) HIP_TRY(c, c->d_gv[k].alloc(P)); }
     for (int k = 0; k < 2; k++) if (c->d_ck[k].n < P) HIP_TRY(c, c->d_ck[k].alloc(P));
-    if (c->d_gpos.n < (size_t)P * 3) HIP_TRY(c, c->d_gpos.alloc((size_t)P * 3));
     const size_t PS = (size_t)P + 4096;   // segments are laid out as if every chunk of a producer's loop were full: up to one chunk of slack
     for (int k = 0; k < 4; k++) if (c->d_stage[k].n < PS) HIP_TRY(c, c->d_stage[k].alloc(PS));
     if (c->d_stage_pos.n < PS * 3) HIP_TRY(c, c->d_stage_pos.alloc(PS * 3));
@@ -1409,8 +1420,8 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             memset(&job, 0, sizeof job);
             job.st[0] = {c->d_stage[0].p, q_shade, 1}; job.n_streams[0] = 1; job.kind[0] = QC_SHADE; job.total_field[0] = 0;
             job.st[1] = {c->d_stage[1].p, qfree_out, 1}; job.n_streams[1] = 1; job.kind[1] = QC_FREE; job.total_field[1] = 4;
-            job.kind[2] = -1;
-            stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, job, bc, c->d_segs.p, (uint32_t)G.trace, ctl); stage_end(c);
+            job.kind[2] = -1; job.gather_queue = -1;
+            stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, c->S, job, bc, c->d_segs.p, (uint32_t)G.trace, ctl); stage_end(c);
         }
         // shade: continuing rays (slot + key) -> staging 0 / 1, gather queries (slot + position) -> staging 2 / pos, finished paths -> staging 3
         HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
@@ -1422,12 +1433,13 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             // streams in queue order: [0] continuing slot, [1] its coherence key, [2] gather slot, [3] gather position (3 doubles = 6 words), [4] freed slot
             job.st[0] = {c->d_stage[0].p, c->d_cv.p, 1}; job.st[1] = {c->d_stage[1].p, c->d_ck[0].p, 1};
             job.n_streams[0] = 2; job.kind[0] = QC_CONT; job.total_field[0] = 1;
-            job.st[2] = {c->d_stage[2].p, q_gather, 1};
-            job.st[3] = {reinterpret_cast<const uint32_t*>(c->d_stage_pos.p), reinterpret_cast<uint32_t*>(c->d_gpos.p), 6};
-            job.n_streams[1] = 2; job.kind[1] = QC_GATHER; job.total_field[1] = 2;
+            job.st[2] = {c->d_stage[2].p, c->d_gv[0].p, 1};                                                     // gather: slot -> values of the sort by leaf
+            job.st[3] = {reinterpret_cast<const uint32_t*>(c->d_stage_pos.p), c->d_gk[0].p, 6};                 //         position -> key (leaf)
+            job.n_streams[1] = 2; job.kind[1] = QC_GATHER; job.total_field[1] = 2; job.gather_queue = c->S.n_pnode > 0 ? 1 : -1;
+            if (c->S.n_pnode <= 0) job.kind[1] = -1;                                                            // no photon map: no gather queries
             job.st[4] = {c->d_stage[3].p, qfree_out, 1};
             job.n_streams[2] = 1; job.kind[2] = QC_FREE; job.total_field[2] = 3; job.free_base_from_trace = 1;
-            stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, job, bc, c->d_segs.p, (uint32_t)G.shade, ctl); stage_end(c);
+            stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, c->S, job, bc, c->d_segs.p, (uint32_t)G.shade, ctl); stage_end(c);
         }
         launches += 4;
         HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
@@ -1436,13 +1448,12 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         if (c->S.n_pnode > 0 && n_gather > 0) {
             int bits = 1;
             while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
-            stage_begin(c, STG_SORT); hipLaunchKernelGGL(k_st_gkeys, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, c->d_gpos.p, q_gather, ctl, c->d_gk[0].p, c->d_gv[0].p); stage_end(c);
             size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
             HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
             stage_end(c);
             stage_begin(c, STG_GATHER); hipLaunchKernelGGL(k_st_gather, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather); stage_end(c);
-            launches += 3;
+            launches += 2;
         }
         n_cont = c->h_ctl->n_cont;
         n_free = c->h_ctl->n_free;
@@ -1471,7 +1482,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = c->d_pool.n * sizeof(PathRec) + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7;   // ours, re-usable
-            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 24 + 40;   // record, sample id, 13 queue / key words, sort scratch, gather position, staging queues
+            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 40;   // record, sample id, 13 queue / key words, sort scratch, staging queues
             const size_t lbuf = (size_t)n_pix * (size_t)std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)) * 24;
             const size_t avail = (size_t)((double)(free_b + held) * 0.80);
             if (avail > lbuf) slots_budget = std::min(slots_budget, (avail - lbuf) / per_slot);
