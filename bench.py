@@ -198,8 +198,7 @@ def main():
         t0 = time.time()
         n_photons = 0
         if photons > 0 and scene.desc().n_light > 0:
-            ph, _ = rt.tracePhotons(photons)
-            n_photons = len(ph)
+            n_photons, _ = rt.tracePhotonsOnDevice(photons)    # emission, octree and candidate ranges on the device: the photons never visit the host
         setup_s = time.time() - t0
         stripe_h = STRIPE_H if world > 1 else h
         p = rt.params(w, h, stripe_h=stripe_h, rank=rank, world=world, min_samples=spp, max_samples=spp)
@@ -230,15 +229,19 @@ def main():
             elapsed, kernel_ms_avg = float(tt[0].item()), float(tt[1].item())
         stages = {k: float(np.mean([s[k] for s in stage_ms])) for k in stage_ms[0]} if stage_ms else {}
         img = fg.frame.cpu().numpy() if rank == 0 else None
-        return {"scene": scene, "rt": rt, "elapsed": elapsed, "kernel_ms": kernel_ms_avg, "stages": stages, "img": img, "rows": rows, "n_photons": n_photons, "setup_s": setup_s}
+        return {"scene": scene, "rt": rt, "elapsed": elapsed, "kernel_ms": kernel_ms_avg, "stages": stages, "img": img, "rows": rows, "n_photons": n_photons, "photons_asked": photons, "setup_s": setup_s}
 
     def cpu_leg(res, scene_name, w, h, spp, budget_s, cores):
         """The oracle (the checker) timed on the host cores on full-width rows spread over the frame; returns (cpu_baseline, mix, rmse)."""
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import parity_checks as pc
         o = pc.oracle_for(res["scene"])
-        o.set_photons(res["scene"].photon_tables()["photons"]).build_photon_map()
         rt = res["rt"]
+        ph = np.zeros((0, 9))
+        if res["n_photons"] > 0:
+            ph, _ = rt.tracePhotons(res["photons_asked"])      # the same keyed photon set, this time brought to the host for the oracle
+            assert len(ph) == res["n_photons"]
+        o.set_photons(ph).build_photon_map()
         n_rows = args.cpu_rows
         if n_rows < 0 or budget_s != CPU_BUDGET_S:
             probe = np.unique(np.linspace(0, h - 1, cores).round().astype(np.int32))   # calibrate on one row per core, then size the sample

@@ -58,7 +58,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
     "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
-    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays",
+    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
     "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_texture", "gih_add_material_tex", "gih_load_png", "gih_free",
@@ -102,6 +102,11 @@ def lib():
     L.gi_halton_index.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _up, _up]
     L.gi_debug_leaf_order.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _ip]
     L.gi_kat.argtypes = [vp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp]
+    L.gi_clear_photons.argtypes = [vp]
+    L.gi_group_clear_photons.argtypes = [vp]
+    L.gi_build_photon_map.argtypes = [vp, C.c_int32, _dp, _dp]
+    L.gi_trace_photons.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint64, _dp, C.POINTER(C.c_int64)]
+    L.gi_debug_photon_tables.argtypes = [vp, _ip, _ip, _ip, vp, _ip, _dp, _dp]
     L.gi_group_create.argtypes = [C.POINTER(vp), C.c_int32, _ip]
     L.gi_group_destroy.argtypes = [vp]
     L.gi_group_size.argtypes = [vp]
@@ -360,6 +365,7 @@ class RayTracerGroup:
     def setScene(self, scene, photons=None):
         d = scene.desc()
         self._check(self.L.gi_group_upload_scene(self.h, C.byref(d)), "group upload_scene")
+        self.L.gi_group_clear_photons(self.h)
         if photons is not None:
             scene.build_photon_map(photons)
             pd = scene.photon_desc()
@@ -416,6 +422,7 @@ class RayTracer:
         """RayTracer::setScene (include/raytracer.h:35-39) + upload of the flattened tables."""
         d = scene.desc()
         self._check(self.L.gi_upload_scene(self.h, C.byref(d)), "upload_scene")
+        self._check(self.L.gi_clear_photons(self.h), "clear_photons")      # a fresh PhotonMap, as RayTracer::setScene allocates
         self.scene = scene
         if adopt_settings:
             st = scene.settings
@@ -442,6 +449,29 @@ class RayTracer:
         self.scene.build_photon_map(ph)
         self.upload_photon_map()
         return ph, tries.value
+
+    def build_photon_map_on_device(self, photons, box=None):
+        """gi_build_photon_map: the photon octree and its candidate ranges built on the device from photons [n][9]."""
+        ph = _f64(photons).reshape(-1, 9)
+        b = _f64(box) if box is not None else None
+        self._check(self.L.gi_build_photon_map(self.h, len(ph), _p(ph), _p(b)), "build_photon_map")
+
+    def tracePhotonsOnDevice(self, count=None, max_depth=5, seed=None):
+        """gi_trace_photons: emission and photon-map build without leaving the device; returns (photons stored, emission tries)."""
+        count = self.photons if count is None else count
+        tries = C.c_int64()
+        n = self._check(self.L.gi_trace_photons(self.h, count, max_depth, C.c_uint64(self.seed if seed is None else seed), None, C.byref(tries)), "trace_photons")
+        return n, tries.value
+
+    def photon_tables_on_device(self):
+        """The photon-map tables as the gather kernel sees them (gi_debug_photon_tables)."""
+        nn, nr, nph = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.L.gi_debug_photon_tables(self.h, C.byref(nn), C.byref(nr), C.byref(nph), None, None, None, None), "photon_tables")
+        nodes = np.zeros((nn.value, 128), np.uint8); ranges = np.zeros((nr.value, 2), np.int32)
+        pos = np.zeros((nph.value, 3)); dircol = np.zeros((nph.value, 6))
+        if nn.value:
+            self._check(self.L.gi_debug_photon_tables(self.h, None, None, None, nodes.ctypes.data_as(C.c_void_p), _p(ranges, _ip), _p(pos), _p(dircol)), "photon_tables")
+        return {"nodes": nodes, "ranges": ranges, "pos": pos, "dircol": dircol}
 
     def params(self, w, h, stripe_h=None, rank=0, world=1, min_samples=None, max_samples=None, noise_thresh=None, seed=None):
         p = RenderParams()

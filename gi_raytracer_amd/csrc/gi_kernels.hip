@@ -1012,6 +1012,7 @@ struct gi_ctx {
     DevBuf<int32_t> d_wleaf_id;
     bool wide_enabled = true;         // gi_set_wide_nodes
     bool pn_planes_ok = false;        // the uploaded photon octree qualifies for the one-record-per-level descent
+    int32_t n_prange = 0;             // entries of d_pranges in use
     DevBuf<int32_t> d_refs;
     DevBuf<LeafTri> d_leaf_tris;
     DevBuf<TriGeom> d_tris;
@@ -1082,6 +1083,8 @@ int fail(gi_ctx* c, int code, const std::string& msg)
     } while (0)
 
 }  // namespace
+
+#include "gi_photon_build.inc"
 
 extern "C" {
 
@@ -1181,9 +1184,17 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     S.fogs = c->d_fogs.p; S.fog_grid = c->d_fog_grid.p; S.n_fog = H.n_fog();
     for (const TriGeom& g : H.tris) if (g.flags & 4u) S.has_spheres = 1;
     for (int k = 0; k < 3; k++) S.ambient[k] = H.ambient[k];
-    // a new scene invalidates the photon map (RayTracer::setScene allocates a fresh PhotonMap, include/raytracer.h:38)
-    S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0;
+    // the photon map stays as it is: the reference keeps a valid map when the scene is edited and rebuilt (include/raytracer.h:56-72);
+    // RayTracer::setScene, which allocates a fresh PhotonMap (include/raytracer.h:38), is gi_upload_scene + gi_clear_photons
     c->have_scene = true;
+    return GI_OK;
+}
+
+int gi_clear_photons(gi_ctx* c)
+{
+    if (!c) return GI_E_INVALID;
+    Scene& S = c->S;
+    S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0;
     return GI_OK;
 }
 
@@ -1202,6 +1213,7 @@ int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
     }
     HIP_TRY(c, c->d_pnodes.upload(H.nodes));
     HIP_TRY(c, c->d_pranges.upload(H.ranges));
+    c->n_prange = (int32_t)H.ranges.size();
     HIP_TRY(c, c->d_ph_pos.upload(H.pos));
     HIP_TRY(c, c->d_ph_dircol.upload(H.dircol));
     S.pnodes = c->d_pnodes.p; S.pranges = c->d_pranges.p; S.ph_pos = c->d_ph_pos.p; S.ph_dircol = c->d_ph_dircol.p;
@@ -1815,6 +1827,76 @@ int gi_emit_photons(gi_ctx* c, int32_t count, int32_t max_depth, uint64_t seed, 
     return stored;
 }
 
+int gi_build_photon_map(gi_ctx* c, int32_t n, const double* photons, const double* box6)
+{
+    if (!c || n < 0 || (n && !photons)) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "build_photon_map: no scene uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double box[6];
+    for (int k = 0; k < 3; k++) { box[k] = box6 ? box6[k] : c->S.root_bmin[k]; box[3 + k] = box6 ? box6[3 + k] : c->S.root_bmax[k]; }
+    DevBuf<double> d_ph;
+    if (n) HIP_TRY(c, d_ph.upload(std::vector<double>(photons, photons + (size_t)n * 9)));
+    return build_photon_map_on_device(c, d_ph.p, n, box);
+}
+
+int gi_trace_photons(gi_ctx* c, int32_t count, int32_t max_depth, uint64_t seed, const double* box6, int64_t* tries_out)
+{
+    if (!c || count < 0) return GI_E_INVALID;
+    if (!c->have_scene) return fail(c, GI_E_STATE, "trace_photons: no scene uploaded");
+    const long long total = (long long)count * c->S.n_light;
+    if (tries_out) *tries_out = 0;
+    if (total > 0x7fffffffLL) return fail(c, GI_E_INVALID, "trace_photons: count too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    double box[6];
+    for (int k = 0; k < 3; k++) { box[k] = box6 ? box6[k] : c->S.root_bmin[k]; box[3 + k] = box6 ? box6[3 + k] : c->S.root_bmax[k]; }
+    if (total == 0) { const int rc = build_photon_map_on_device(c, nullptr, 0, box); return rc < 0 ? rc : 0; }
+    DevBuf<PhotonOut> d_p;
+    DevBuf<int32_t> d_s, d_t, d_x;
+    HIP_TRY(c, d_p.alloc((size_t)total)); HIP_TRY(c, d_s.alloc((size_t)total)); HIP_TRY(c, d_t.alloc((size_t)total)); HIP_TRY(c, d_x.alloc((size_t)total));
+    hipLaunchKernelGGL(k_emit, GI_GRID(total), 0, c->stream, c->S, count, max_depth, seed, d_p.p, d_s.p, d_t.p);
+    // stored photons in (photon index, light) order = the order one reference thread appends them (include/raytracer.h:593-706)
+    size_t tb = 0;
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_s.p, d_x.p, (int)total, c->stream));
+    DevBuf<unsigned char> d_tmp;
+    HIP_TRY(c, d_tmp.alloc(tb));
+    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb, d_s.p, d_x.p, (int)total, c->stream));
+    int32_t last_x = 0, last_s = 0;
+    HIP_TRY(c, hipMemcpyAsync(&last_x, d_x.p + (total - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&last_s, d_s.p + (total - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int32_t n = last_x + last_s;
+    if (tries_out) {      // total emission tries (diagnostic): summed on the host from the per-index counts
+        std::vector<int32_t> ht((size_t)total);
+        HIP_TRY(c, hipMemcpy(ht.data(), d_t.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        int64_t tries = 0;
+        for (int32_t v : ht) tries += v;
+        *tries_out = tries;
+    }
+    DevBuf<double> d_ph;
+    HIP_TRY(c, d_ph.alloc((size_t)std::max(n, 1) * 9));
+    hipLaunchKernelGGL(k_pb_compact_emitted, GI_GRID(total), 0, c->stream, d_p.p, d_s.p, d_x.p, (uint32_t)total, d_ph.p);
+    HIP_TRY(c, hipGetLastError());
+    const int rc = build_photon_map_on_device(c, d_ph.p, n, box);
+    return rc < 0 ? rc : n;
+}
+
+int gi_debug_photon_tables(gi_ctx* c, int32_t* n_node, int32_t* n_range, int32_t* n_photon, void* nodes128, int32_t* ranges2, double* pos3, double* dircol6)
+{
+    if (!c) return GI_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const Scene& S = c->S;
+    if (n_node) *n_node = S.n_pnode;
+    if (n_range) *n_range = S.n_pnode > 0 ? c->n_prange : 0;
+    if (n_photon) *n_photon = S.n_photon;
+    if (S.n_pnode <= 0) return GI_OK;
+    if (nodes128) HIP_TRY(c, hipMemcpy(nodes128, S.pnodes, (size_t)S.n_pnode * sizeof(PNode), hipMemcpyDeviceToHost));
+    if (ranges2) HIP_TRY(c, hipMemcpy(ranges2, S.pranges, (size_t)c->n_prange * sizeof(PRange), hipMemcpyDeviceToHost));
+    if (pos3 && S.n_photon) HIP_TRY(c, hipMemcpy(pos3, S.ph_pos, (size_t)S.n_photon * 24, hipMemcpyDeviceToHost));
+    if (dircol6 && S.n_photon) HIP_TRY(c, hipMemcpy(dircol6, S.ph_dircol, (size_t)S.n_photon * 48, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
 int gi_debug_leaf_order(gi_ctx* c, int32_t n, const double* rays, int32_t cap, int32_t* leaf_out, int32_t* n_out)
 {
     if (!c || n < 0 || cap < 1 || (n && (!rays || !leaf_out || !n_out))) return GI_E_INVALID;
@@ -1958,6 +2040,12 @@ int gi_group_upload_scene(gi_group* g, const gi_scene_desc* d)
 {
     if (!g) return GI_E_INVALID;
     for (gi_ctx* c : g->ctx) { const int rc = gi_upload_scene(c, d); if (rc) return group_fail(g, rc, gi_last_error(c)); }
+    return GI_OK;
+}
+int gi_group_clear_photons(gi_group* g)
+{
+    if (!g) return GI_E_INVALID;
+    for (gi_ctx* c : g->ctx) gi_clear_photons(c);
     return GI_OK;
 }
 int gi_group_upload_photons(gi_group* g, const gi_photon_map_desc* d)

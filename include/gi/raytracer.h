@@ -41,6 +41,7 @@ class RayTracer {
         _st->photon_map = std::make_shared<PhotonMap>(scene->_root._bbox.min, scene->_root._bbox.max);
         _st->uploaded = false;
         _st->photons_uploaded = false;
+        _st->fresh_map = true;
     }
 
     // RayTracer::run(w, h), include/raytracer.h:41-165
@@ -209,6 +210,7 @@ class RayTracer {
     int progressive_rows = 16;                // rows per displayed stripe of run(); 0 = the whole frame in one call
     std::vector<int32_t> devices;             // HIP device ordinals to render on; empty = every visible GPU (the frame's stripes are dealt round-robin)
     volatile int rows_done = 0;               // rows of the current frame already in the Image
+    int photons_on_device = 0;                // photons stored by the last on-device emission of run()
 
     std::shared_ptr<Image> getImage() const { return _image; }
     const std::vector<float>& linear() const { return _linear; }   // float tap of the frame (pre-gamma)
@@ -221,7 +223,7 @@ class RayTracer {
         gi_ctx* ctx = nullptr;        // the context of the per-ray methods and of photon emission; member 0 of the group when there is one
         gi_group* group = nullptr;    // every visible GPU, when there is more than one (or `devices` says so)
         std::shared_ptr<PhotonMap> photon_map;
-        bool uploaded = false, photons_uploaded = false;
+        bool uploaded = false, photons_uploaded = false, fresh_map = true;
         std::string err;
         ~State() { if (group) gi_group_destroy(group); else if (ctx) gi_destroy(ctx); }
     };
@@ -255,7 +257,21 @@ class RayTracer {
         PhotonMap* pm = _st->photon_map.get();
         if (!pm) return true;
         if (!pm->valid) {
-            if (pm->size() == 0) tracePhotons(5, photons);          // include/raytracer.h:61-72
+            if (pm->size() == 0) {
+                // nothing pushed by a caller: RayTracer::run's tracePhotons + rebuild (include/raytracer.h:61-72) entirely on the device(s) --
+                // emission, octree, candidate ranges; the photons never visit the host (every device emits the same keyed set)
+                const double box[6] = {pm->_root._bbox.min.x, pm->_root._bbox.min.y, pm->_root._bbox.min.z, pm->_root._bbox.max.x, pm->_root._bbox.max.y, pm->_root._bbox.max.z};
+                const int members = _st->group ? gi_group_size(_st->group) : 1;
+                for (int i = 0; i < members; i++) {
+                    gi_ctx* cx = _st->group ? gi_group_ctx(_st->group, i) : _st->ctx;
+                    const int n = gi_trace_photons(cx, _scene->lights.empty() ? 0 : photons, 5, seed, box, nullptr);
+                    if (n < 0) { _st->err = gi_last_error(cx); fprintf(stderr, "gi: %s\n", _st->err.c_str()); return false; }
+                    photons_on_device = n;
+                }
+                pm->valid = true;
+                _st->photons_uploaded = true;
+                return true;
+            }
             pm->rebuild();
             _st->photons_uploaded = false;
         }
@@ -276,7 +292,7 @@ class RayTracer {
         if (gih_get_scene_desc(_scene->handle(), &d) != 0) { _st->err = "scene octree not built"; return false; }
         if (check(_st->group ? gi_group_upload_scene(_st->group, &d) : gi_upload_scene(_st->ctx, &d)) != 0) return false;
         _st->uploaded = true;
-        _st->photons_uploaded = false;   // a scene upload drops the device copy of the photon map; the host map stays valid and is sent again
+        if (_st->fresh_map) { if (_st->group) gi_group_clear_photons(_st->group); else gi_clear_photons(_st->ctx); _st->fresh_map = false; }   // setScene: a fresh PhotonMap; an edited scene keeps its map
         return true;
     }
     int check(int rc)

@@ -101,8 +101,11 @@ int gi_set_stream(gi_ctx*, void* hip_stream);
 /* replaces: RayTracer::setScene + the tree walk of Octree::intersect/intersectSorted (include/raytracer.h:35-39,
  * include/octree.cpp:150-211,256-313) -- uploads the tables every kernel reads                                           */
 int gi_upload_scene(gi_ctx*, const gi_scene_desc*);
-/* replaces: PhotonMap::push_back/rebuild as the source of the gather (include/photonMap.cpp:24-47)                         */
+/* replaces: PhotonMap::push_back/rebuild as the source of the gather (include/photonMap.cpp:24-47).  The map outlives gi_upload_scene
+ * (the reference keeps a valid map when an edited scene is rebuilt, include/raytracer.h:56-72); gi_clear_photons drops it -- RayTracer::setScene,
+ * which allocates a fresh PhotonMap (include/raytracer.h:38), is gi_upload_scene + gi_clear_photons.                                    */
 int gi_upload_photons(gi_ctx*, const gi_photon_map_desc*);
+int gi_clear_photons(gi_ctx*);
 
 /* replaces: the pixel loop of RayTracer::run (include/raytracer.h:93-160) with radiance/trace/visible/secondaryRay/
  * samplePhotons inside (include/raytracer.h:167-579).
@@ -159,6 +162,17 @@ int gi_emit_photons(gi_ctx*, int32_t count, int32_t max_depth, uint64_t seed, do
 int gi_halton_sample(gi_ctx*, int32_t n, const uint32_t* dim, const uint32_t* index, float* out);
 int gi_halton_index(gi_ctx*, int32_t width, int32_t height, int32_t n, const uint32_t* sxy /*[n][3]*/, uint32_t* out);
 
+/* The photon map built on the device.  replaces: PhotonMap::push_back x n + PhotonMap::rebuild / PhotonMap::Node::partition
+ * (include/photonMap.cpp:24-47,137-192) and the upload, for photons handed in (gi_build_photon_map: photons [n][9] on the host) or emitted
+ * by the device itself (gi_trace_photons = RayTracer::tracePhotons(max_depth, count) + rebuild, include/raytracer.h:61-72,582-715: the
+ * photons never leave the device; returns the number stored, tries_out = emission tries).  box6 = the box of the map (PhotonMap(min, max));
+ * NULL = the root box of the uploaded scene (RayTracer::setScene, include/raytracer.h:38).  The tables are, byte for byte, the ones
+ * gi_upload_photons derives from the host builder's tree.  gi_debug_photon_tables copies the installed tables back (NULL pointers: sizes only):
+ * nodes128 [n_node][128 bytes], ranges2 [n_range][2], pos3 [n_photon][3], dircol6 [n_photon][6].                                      */
+int gi_build_photon_map(gi_ctx*, int32_t n, const double* photons, const double* box6);
+int gi_trace_photons(gi_ctx*, int32_t count, int32_t max_depth, uint64_t seed, const double* box6, int64_t* tries_out);
+int gi_debug_photon_tables(gi_ctx*, int32_t* n_node, int32_t* n_range, int32_t* n_photon, void* nodes128, int32_t* ranges2, double* pos3, double* dircol6);
+
 /* Several GPUs from one process.  Replaces the OpenMP row loop of RayTracer::run (include/raytracer.h:93: `#pragma omp parallel for
  * schedule(dynamic, 10)` over image rows) for a caller that is one process -- the Qt application: a group holds one context per device, the
  * scene and photon tables are replicated, the frame's stripes of stripe_h rows are dealt round-robin to the devices, each rendered on its own
@@ -179,6 +193,7 @@ gi_ctx* gi_group_ctx(gi_group*, int32_t i);
 const char* gi_group_last_error(const gi_group*);
 int gi_group_upload_scene(gi_group*, const gi_scene_desc*);
 int gi_group_upload_photons(gi_group*, const gi_photon_map_desc*);
+int gi_group_clear_photons(gi_group*);
 int gi_group_render_host(gi_group*, const gi_render_params*, int32_t stripe_h, int32_t first_stripe, int32_t n_stripes, void* h_frame, int out_is_f64, int32_t* h_spp, volatile const int* cancel);
 int gi_group_render_device(gi_group*, const gi_render_params*, int32_t stripe_h, void* d_frame_on_device0, int out_is_f64, volatile const int* cancel);
 

@@ -62,10 +62,10 @@ int main(int argc, char** argv)
         if (argc > 4) printf("saved %d %d\n", (int)img->save_ppm((std::string(argv[4]) + ".ppm").c_str()), (int)gi_save_pfm((std::string(argv[4]) + ".pfm").c_str(), copy.linear().data(), 64, 36));
         // a second frame after a scene edit: the scene is rebuilt and uploaded again, the photon map is kept (the reference keeps a valid map
         // across frames and never emits twice, include/raytracer.h:61-72)
-        const int photons_before = copy.photonMap()->size();
+        const int photons_before = copy.photons_on_device;
         scene->push_back(new triangle(vertex(gi::dvec3(0, 2, 0)), vertex(gi::dvec3(.1, 2, 0)), vertex(gi::dvec3(0, 2, .1)), mat));
         copy.run(64, 36);
-        printf("photons before %d after %d valid %d\n", photons_before, copy.photonMap()->size(), (int)scene->valid);
+        printf("photons before %d after %d valid %d\n", photons_before, copy.photons_on_device, (int)scene->valid);
         // ---- progressive display + cancellation (viewer.h:18-21,36-39, raytracer.h:93-160): the worker fills the shared image stripe by stripe,
         // the "GUI" thread watches it and then stops it
         RayTracer live = raytracer;

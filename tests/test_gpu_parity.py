@@ -370,6 +370,66 @@ def test_config5_standin_fog_photons_large_tree():
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
 
 
+def _tables_equal(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in ("nodes", "ranges", "pos", "dircol"))
+
+
+@pytest.mark.parametrize("name", ["cornell", "caustics", "caustics_02"])
+def test_device_photon_map_build_equals_host_builder(name, golden):
+    """SURVEY 8 f2: PhotonMap::rebuild / Node::partition (include/photonMap.cpp:33-47,137-192) on the device (gi_build_photon_map): the tables
+    the gather kernel reads -- node records, candidate ranges, photons in leaf order -- equal, byte for byte, the ones gi_upload_photons derives
+    from the host builder's tree (itself node for node the reference's, tests/test_host_builders.py), on the reference's own photon sets."""
+    fx = golden("scene_" + name)
+    scene = pc.load_scene(name)
+    rt = gi.RayTracer(0).setScene(scene)
+    scene.build_photon_map(fx["photons"])
+    rt.upload_photon_map()
+    host = rt.photon_tables_on_device()
+    res_h, nc_h = rt.samplePhotons(fx["gather_q"])
+    rt.build_photon_map_on_device(fx["photons"])
+    dev = rt.photon_tables_on_device()
+    assert len(host["nodes"]) > 100 and _tables_equal(host, dev)
+    res_d, nc_d = rt.samplePhotons(fx["gather_q"])
+    assert np.array_equal(nc_d, fx["gather_ncand"]) and np.array_equal(res_d.view(np.uint64), res_h.view(np.uint64))
+
+
+def test_device_photon_map_build_edge_cases_and_size():
+    """Few photons (the root stays a leaf), photons outside the box (no child contains them: dropped at the first split), a cluster that splits
+    deep, a million photons; and emission + build without leaving the device (gi_trace_photons) against the host hop."""
+    scene = pc.load_scene("caustics")
+    rt = gi.RayTracer(0).setScene(scene)
+    bb = scene.tables()["node_bbox"][0]
+    rs = np.random.RandomState(11)
+
+    def photons(n, spread=1.0, centre=None):
+        c = (bb[:3] + bb[3:]) / 2 if centre is None else centre
+        pos = c + (rs.rand(n, 3) - 0.5) * (bb[3:] - bb[:3]) * spread
+        d = rs.randn(n, 3); d /= np.linalg.norm(d, axis=1)[:, None]
+        return np.concatenate([pos, d, rs.rand(n, 3)], 1)
+
+    cases = {"few": photons(10), "seventeen": photons(17), "outside": photons(3000, spread=1.6), "cluster": np.concatenate([photons(2000), photons(4000, spread=1e-4)]),
+             "million": photons(1000000)}
+    for label, ph in cases.items():
+        scene.build_photon_map(ph)
+        rt.upload_photon_map()
+        host = rt.photon_tables_on_device()
+        rt.build_photon_map_on_device(ph)
+        dev = rt.photon_tables_on_device()
+        assert _tables_equal(host, dev), label
+    assert len(host["nodes"]) > 100000                       # the million-photon tree
+    # an empty set: no map, the gather returns 0
+    rt.build_photon_map_on_device(np.zeros((0, 9)))
+    assert rt.samplePhotons(np.array([[0.0, 0.1, 0.0, 0, 1, 0]]))[0].max() == 0
+    # emission on the device + build on the device == emission, host build, upload
+    ph, tries = rt.tracePhotons(20000)
+    host = rt.photon_tables_on_device()
+    n, tries_d = rt.tracePhotonsOnDevice(20000)
+    assert n == len(ph) and tries_d == tries and _tables_equal(host, rt.photon_tables_on_device())
+    img_a = rt.run(64, 36, min_samples=4, max_samples=4)
+    rt.tracePhotons(20000)
+    assert np.array_equal(img_a, rt.run(64, 36, min_samples=4, max_samples=4))
+
+
 def test_group_of_contexts_renders_the_single_context_frame():
     """gi_group_* (include/gi_hip.h): one process, several contexts, one host thread each, stripes dealt round-robin and gathered -- the C path a
     C++ caller gets on a multi-GPU node.  On this one-GPU box the group holds three contexts on device 0: the frame must equal the single
