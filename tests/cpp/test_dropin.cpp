@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include "../../include/gi/builtin_loaders.h"
@@ -88,7 +89,7 @@ int main(int argc, char** argv)
             const int done = live.rows_done, f = filled_rows();
             if (f < last) monotone = 0;
             if (f > 0 && f < H) partial_seen = 1;
-            if (f > done + 16) monotone = 0;                       // nothing beyond the stripe in flight is ever painted
+            if (f > done + 16 * (int)std::max<size_t>(1, live.devices.size())) monotone = 0;   // nothing beyond the stripes in flight (one per device) is ever painted
             last = f; polls++;
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
