@@ -57,7 +57,7 @@ _LIB = None
 # every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
-    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
+    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
     "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
@@ -88,6 +88,7 @@ def lib():
     L.gi_render_host.argtypes = [vp, C.POINTER(RenderParams), vp, C.c_int, vp, vp]
     L.gi_set_render_mode.argtypes = [vp, C.c_int]
     L.gi_set_wide_nodes.argtypes = [vp, C.c_int]
+    L.gi_set_content_culling.argtypes = [vp, C.c_int]
     L.gi_set_pool_slots.argtypes = [vp, C.c_int64]
     L.gi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), _ip]
     L.gi_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -513,6 +514,10 @@ class RayTracer:
             self._check(rc, "set_wide_nodes")
         self.photon_planes = bool(rc & 2)      # the photon octree's one-record-per-level descent is in use
         return bool(rc & 1)
+
+    def set_content_culling(self, on):
+        """Skip children of the octree walk in whose sub-tree the ray cannot hit anything (default on); returns whether it is in use."""
+        return bool(self._check(self.L.gi_set_content_culling(self.h, 1 if on else 0), "set_content_culling"))
 
     def set_pool_slots(self, slots):
         self._check(self.L.gi_set_pool_slots(self.h, int(slots)), "set_pool_slots")

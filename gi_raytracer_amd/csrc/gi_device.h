@@ -121,6 +121,8 @@ struct Scene {
     const TNode* tnodes;      // [n_node]
     const WNode* wnodes;      // [n_wnode] inner nodes, breadth first; null when the tree is not made of exact octants
     const int32_t* wleaf_id;  // [n_wnode][8] canonical node index of a leaf child (RNG key of the alpha test)
+    const float* cboxes;      // [n_wnode][8][6] content box of every child's sub-tree (all entities referenced below it), rounded outwards; null = no culling
+    const uint32_t* cuse;     // [n_wnode] children (slot bits) whose content box is worth testing (clearly smaller than their octant)
     const int32_t* leaf_refs;
     const LeafTri* leaf_tris; // [n_refs], parallel to leaf_refs
     const TriGeom* tris;
@@ -590,13 +592,48 @@ struct GlobalNodes {
 // their parent.  BoundingBox::intersect updates tmin upwards and tmax downwards axis by axis and leaves at the first
 // tmax <= tmin (include/bbox.h:47-73); both are monotone, so it returns false exactly when the final tmax <= tmin, and
 // `t0 > tmin ? t0 : tmin` is maxNum (a NaN from 0 * inf is ignored), which is what fmax / v_max_f64 compute.
-struct WRay { int off[3]; int a; };   // per axis: 8 when the ray runs backwards along it (invDir < 0), else 0; a = direction octant
+struct WRay { int off[3]; int a; double tc; };   // per axis: 8 when the ray runs backwards along it (invDir < 0), else 0; a = direction octant;
+                                                  // tc = parameter beyond which no hit can count (content-box culling)
 GI_HD WRay wray_make(const Ray& r)
 {
     WRay w;
     w.off[0] = r.inv.x < 0.0 ? 8 : 0; w.off[1] = r.inv.y < 0.0 ? 8 : 0; w.off[2] = r.inv.z < 0.0 ? 8 : 0;
     w.a = (r.d.x < 0.0 ? 1 : 0) | (r.d.z < 0.0 ? 2 : 0) | (r.d.y < 0.0 ? 4 : 0);
+    w.tc = INFINITY;
     return w;
+}
+// Content-box culling.  The reference's octree cuts space, not content: a leaf that holds a piece of the floor spans its whole octant, and
+// a ray passing over the floor has to test every triangle in it.  Next to every child's octant box (the reference's test, unchanged) the
+// wide records carry the box of everything REFERENCED in that child's sub-tree -- the union of the entities' own boxes, widened by a margin
+// a billion times the rounding of a hit point and rounded outwards to float.  A child whose octant the ray enters is skipped when the ray
+// misses that box inside [0, tc]: no entity below it can then report a hit (a hit lies on its entity, at t >= 0 and, for a shadow ray,
+// before the light), so every hit the reference records is still recorded, in the same order, and the walk stops after the same leaf --
+// same results by construction (frames with and without culling are compared bit for bit, gi_set_content_culling).  What it saves is the
+// visits that could not have mattered: in the benchmark 96 % of the reflected rays leave the scene, and their walks shrink to a few nodes.
+// m: candidate children in the ray's order (bit k = slot k ^ a); returns m without the children the ray cannot hit anything in.
+GI_HD uint32_t content_cull(const float* cboxes, const uint32_t* cuse, int32_t node, uint32_t m, const Ray& r, const WRay& wr)
+{
+    uint32_t u = cuse[node];
+    if (wr.a & 1) u = ((u & 0x55u) << 1) | ((u >> 1) & 0x55u);      // slot bits -> the ray's order, as wide_hits does
+    if (wr.a & 2) u = ((u & 0x33u) << 2) | ((u >> 2) & 0x33u);
+    if (wr.a & 4) u = ((u & 0x0fu) << 4) | ((u >> 4) & 0x0fu);
+    uint32_t todo = m & u;
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
+    while (todo) {
+        const int kk = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const float* b = cboxes + ((size_t)node * 8 + (size_t)(kk ^ wr.a)) * 6;
+        double tn = 0.0, tf = wr.tc;
+        for (int ax = 0; ax < 3; ax++) {
+            // entry plane first: a NaN (origin exactly on a plane of an axis the ray does not move along: 0 * inf) is ignored by fmax / fmin,
+            // which is the right answer -- the origin is inside that closed slab
+            const int back = wr.off[ax] ? 3 : 0;
+            tn = fmax(tn, ((double)b[ax + back] - o[ax]) * inv[ax]);
+            tf = fmin(tf, ((double)b[ax + 3 - back] - o[ax]) * inv[ax]);
+        }
+        if (!(tf >= tn)) m &= ~(1u << kk);
+    }
+    return m;
 }
 // bit k of the result: the k-th child in this ray's front-to-back order (slot k ^ a) exists and its box is hit in (tmin0, tmax0)
 GI_HD uint32_t wide_hits(const WNode* w, const Ray& r, const WRay& wr, double tmin0, double tmax0)
@@ -645,6 +682,8 @@ struct GlobalWide {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
     const WNode* g;
+    const float* cboxes = nullptr;      // content boxes (null: the walk visits every child whose octant the ray enters)
+    const uint32_t* cuse = nullptr;
     template <class F> GI_HDM auto with(int32_t i, F&& f) const { return f(g + i); }
 };
 // walk state: the node, the children of it still to visit (bit k = k-th in order), and the same masks of its ancestors, one
@@ -676,6 +715,7 @@ GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr
         if (cb < 0) {
             wwalk_push(k, ca);
             k.m = W.with(ca, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+            if (W.cboxes && k.m) k.m = content_cull(W.cboxes, W.cuse, ca, k.m, ray, wr);
             continue;
         }
         lnode = k.node; lslot = slot; first = ca; cnt = cb;
@@ -688,6 +728,7 @@ GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, co
     k.node = 0; k.m = 0; k.lo = 0; k.hi = 0;
     if (!box_hit(S.root_bmin, S.root_bmax, ray, tmin0, tmax0)) return false;
     k.m = W.with(0, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+    if (W.cboxes && k.m) k.m = content_cull(W.cboxes, W.cuse, 0, k.m, ray, wr);
     return true;
 }
 template <int FEAT, class WN>
@@ -749,8 +790,9 @@ GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rn
 template <int FEAT, class WN>
 GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index)
 {
-    const WRay wr = wray_make(ray);
+    WRay wr = wray_make(ray);
     const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
+    wr.tc = sqrt(mt) * (1.0 + 1e-9);   // a blocker lies before the light: 0 < |hit - o|^2 < mt
     WWalk k;
     if (wwalk_begin(S, W, k, ray, wr, 0.0, tmax)) {
         for (;;) {
@@ -870,8 +912,9 @@ __device__ __forceinline__ bool visible_wide_coop(const Scene& S, const WN& W, c
     if constexpr ((FEAT & GI_FEAT_TEX) != 0) return visible_wide<FEAT>(S, W, ray, mt, rng, light_index);
     else {
     const int lane = (int)(threadIdx.x & 63u);
-    const WRay wr = wray_make(ray);
+    WRay wr = wray_make(ray);
     const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
+    wr.tc = sqrt(mt) * (1.0 + 1e-9);
     WWalk k;
     if (wwalk_begin(S, W, k, ray, wr, 0.0, tmax)) {
         for (;;) {
@@ -987,7 +1030,7 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
     best.tu = 0; best.tv = 0;
     if (S.wnodes && !c) {   // the work counters count the reference's per-node box tests: counted runs take the per-node walk
         GlobalWide W;
-        W.g = S.wnodes;
+        W.g = S.wnodes; W.cboxes = S.cboxes; W.cuse = S.cuse;
         return S.n_tex > 0 ? trace_nodes<7>(S, W, ray, rng, alpha_purpose, best, nullptr) : trace_nodes<3>(S, W, ray, rng, alpha_purpose, best, nullptr);
     }
     GlobalNodes N;
@@ -1056,7 +1099,7 @@ GI_HD bool visible(const Scene& S, const Ray& ray, double mt, const Rng& rng, ui
 {
     if (S.wnodes && !c) {
         GlobalWide W;
-        W.g = S.wnodes;
+        W.g = S.wnodes; W.cboxes = S.cboxes; W.cuse = S.cuse;
         return S.n_tex > 0 ? visible_nodes<7>(S, W, ray, mt, rng, light_index, nullptr) : visible_nodes<3>(S, W, ray, mt, rng, light_index, nullptr);
     }
     GlobalNodes N;
@@ -1443,7 +1486,7 @@ GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     if (S.wnodes && !c) {
         GlobalWide W;
-        W.g = S.wnodes;
+        W.g = S.wnodes; W.cboxes = S.cboxes; W.cuse = S.cuse;
         return S.n_tex > 0 ? stage_trace_nodes<7>(S, W, p, seed, nullptr) : stage_trace_nodes<3>(S, W, p, seed, nullptr);
     }
     GlobalNodes N;
@@ -1580,7 +1623,7 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     if (S.wnodes && !c) {
         GlobalWide W;
-        W.g = S.wnodes;
+        W.g = S.wnodes; W.cboxes = S.cboxes; W.cuse = S.cuse;
         return S.n_tex > 0 ? stage_shade_nodes<7>(S, W, p, seed, nullptr) : stage_shade_nodes<3>(S, W, p, seed, nullptr);
     }
     GlobalNodes N;

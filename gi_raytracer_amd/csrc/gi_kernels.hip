@@ -123,6 +123,8 @@ struct LdsWide {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
     const WNode* g;
+    const float* cboxes;      // content boxes of the children (gi_device.h: content_cull), read through L1 / L2; null = no culling
+    const uint32_t* cuse;
     int32_t n_l;
     template <class F> __device__ __forceinline__ auto with(int32_t i, F&& f) const
     {
@@ -135,6 +137,7 @@ __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S)
 {
     LdsWide N;
     N.g = S.wnodes;
+    N.cboxes = S.cboxes; N.cuse = S.cuse;
     N.n_l = S.n_wnode < GI_LDS_WNODES ? S.n_wnode : GI_LDS_WNODES;
     const uint4* src = reinterpret_cast<const uint4*>(S.wnodes);
     uint4* dst = reinterpret_cast<uint4*>(gi_dyn_lds);
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
         // few enough paths for one wave each: all 64 lanes work on the same path, a leaf's triangles tested side by side
         if (lanes <= 0 && n_in <= coop_factor * n_waves) {
             LdsWideCoop NC;
-            NC.g = N.g; NC.n_l = N.n_l;
+            NC.g = N.g; NC.n_l = N.n_l; NC.cboxes = N.cboxes; NC.cuse = N.cuse;
             for (uint32_t i = wave; i < n_in; i += n_waves) {
                 const uint32_t slot = q_in[i];
                 PathRec p = pool[slot];
@@ -1010,6 +1013,9 @@ struct gi_ctx {
     DevBuf<unsigned char> d_tex_pixels;
     DevBuf<double> d_tex_lut;
     DevBuf<int32_t> d_wleaf_id;
+    DevBuf<float> d_cboxes;           // content boxes of the wide records' children
+    DevBuf<uint32_t> d_cuse;
+    bool cull_enabled = true;         // gi_set_content_culling
     bool wide_enabled = true;         // gi_set_wide_nodes
     bool pn_planes_ok = false;        // the uploaded photon octree qualifies for the one-record-per-level descent
     int32_t n_prange = 0;             // entries of d_pranges in use
@@ -1159,6 +1165,8 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_tnodes.upload(H.tnodes));
     HIP_TRY(c, c->d_wnodes.upload(H.wnodes));
     HIP_TRY(c, c->d_wleaf_id.upload(H.wleaf_id));
+    HIP_TRY(c, c->d_cboxes.upload(H.cboxes));
+    HIP_TRY(c, c->d_cuse.upload(H.cuse));
     HIP_TRY(c, c->d_texs.upload(H.texs));
     HIP_TRY(c, c->d_tri_uv.upload(H.tri_uv));
     HIP_TRY(c, c->d_tex_pixels.upload(H.tex_pixels));
@@ -1179,6 +1187,8 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     S.n_wnode = (int32_t)H.wnodes.size();
     S.wnodes = (c->wide_enabled && S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
     S.wleaf_id = c->d_wleaf_id.p;
+    S.cboxes = (c->cull_enabled && S.wnodes && !H.cboxes.empty()) ? c->d_cboxes.p : nullptr;
+    S.cuse = c->d_cuse.p;
     S.tri_uv = c->d_tri_uv.p; S.texs = c->d_texs.p; S.tex_pixels = c->d_tex_pixels.p; S.tex_lut = c->d_tex_lut.p; S.n_tex = H.n_tex();
     S.has_spheres = 0;
     S.fogs = c->d_fogs.p; S.fog_grid = c->d_fog_grid.p; S.n_fog = H.n_fog();
@@ -1620,8 +1630,17 @@ int gi_set_wide_nodes(gi_ctx* c, int enable)
     if (!c) return GI_E_INVALID;
     c->wide_enabled = enable != 0;
     c->S.wnodes = (c->wide_enabled && c->S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
+    c->S.cboxes = (c->cull_enabled && c->S.wnodes && c->d_cboxes.n > 1) ? c->d_cboxes.p : nullptr;
     c->S.pn_planes = (c->wide_enabled && c->pn_planes_ok) ? 1 : 0;   // the photon octree's counterpart (gather_find_leaf)
     return (c->S.wnodes ? 1 : 0) | (c->S.pn_planes ? 2 : 0);
+}
+
+int gi_set_content_culling(gi_ctx* c, int enable)
+{
+    if (!c) return GI_E_INVALID;
+    c->cull_enabled = enable != 0;
+    c->S.cboxes = (c->cull_enabled && c->S.wnodes && c->d_cboxes.n > 1) ? c->d_cboxes.p : nullptr;
+    return c->S.cboxes ? 1 : 0;
 }
 
 int gi_set_render_mode(gi_ctx* c, int mode)

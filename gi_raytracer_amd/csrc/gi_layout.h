@@ -23,6 +23,8 @@ struct HostScene {
     std::vector<TNode> tnodes;
     std::vector<WNode> wnodes;        // empty when the tree is not made of exact octants (layout_wide)
     std::vector<int32_t> wleaf_id;
+    std::vector<float> cboxes;        // [n_wnode][8][6] content boxes of the children (gi_device.h: content_cull); one dummy entry without wide records
+    std::vector<uint32_t> cuse;       // [n_wnode] children worth testing
     std::vector<int32_t> refs;
     std::vector<LeafTri> leaf_tris;
     std::vector<TriGeom> tris;
@@ -235,6 +237,48 @@ inline bool layout_wide(const gi_scene_desc* d, HostScene& H)
             }
         }
     }
+    // ---- content boxes: for every node the union of the boxes of all entities referenced in its sub-tree (children come later in pre-order)
+    std::vector<double> cb((size_t)N * 6);
+    for (int n = N - 1; n >= 0; n--) {
+        double* b = &cb[(size_t)n * 6];
+        b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY;
+        for (int r = d->node_ent_off[n]; r < d->node_ent_off[n + 1]; r++) {
+            const int e = d->node_ent_idx[r];
+            const double* P = d->tri_pos + (size_t)e * 9;
+            if (d->ent_kind && d->ent_kind[e] == 1) {          // sphere: centre P[0..2], radius P[3]
+                for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], P[ax] - P[3]); b[3 + ax] = std::max(b[3 + ax], P[ax] + P[3]); }
+            } else
+                for (int v = 0; v < 3; v++) for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], P[v * 3 + ax]); b[3 + ax] = std::max(b[3 + ax], P[v * 3 + ax]); }
+        }
+        for (int k = 0; k < 8; k++) {
+            const int ch = d->node_child[(size_t)n * 8 + k];
+            if (ch < 0) continue;
+            for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], cb[(size_t)ch * 6 + ax]); b[3 + ax] = std::max(b[3 + ax], cb[(size_t)ch * 6 + 3 + ax]); }
+        }
+    }
+    double extent = 0;
+    for (int ax = 0; ax < 3; ax++) extent = std::max(extent, d->node_bbox[3 + ax] - d->node_bbox[ax]);
+    const double margin = 1e-7 * std::max(extent, 1e-3);     // a hit point is off its entity by ~1e-16 of its coordinates: eight orders of slack
+    H.cboxes.assign(order.size() * 48, 0.f);
+    H.cuse.assign(order.size(), 0u);
+    for (size_t r = 0; r < order.size(); r++) {
+        const int n = order[r];
+        for (int c = 0; c < 8; c++) {
+            const int ch = d->node_child[(size_t)n * 8 + c];
+            if (ch < 0 || !(W[r].exists & (1u << c))) continue;
+            const double* b = &cb[(size_t)ch * 6];
+            float* out = &H.cboxes[(r * 8 + (size_t)c) * 6];
+            double share = 1.0;                                // how much of the octant the content (clipped to it) fills
+            for (int ax = 0; ax < 3; ax++) {
+                out[ax] = std::nextafterf((float)(b[ax] - margin), -INFINITY);
+                out[3 + ax] = std::nextafterf((float)(b[3 + ax] + margin), INFINITY);
+                const double olo = d->node_bbox[(size_t)ch * 6 + ax], ohi = d->node_bbox[(size_t)ch * 6 + 3 + ax];
+                const double len = std::min((double)out[3 + ax], ohi) - std::max((double)out[ax], olo);
+                share *= ohi > olo ? std::max(0.0, std::min(1.0, len / (ohi - olo))) : 1.0;
+            }
+            if (share < 0.6) H.cuse[r] |= 1u << c;             // the extra test is only made where it can reject something
+        }
+    }
     H.wnodes.swap(W);
     H.wleaf_id.swap(L);
     return true;
@@ -272,7 +316,9 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         t.leaf_id = n;
     }
     for (int a = 0; a < 8; a++) link_octant(d, a, 0, N, rec_of, H.tnodes);
-    layout_wide(d, H);
+    if (!layout_wide(d, H)) { H.wnodes.clear(); H.wleaf_id.clear(); H.cboxes.clear(); H.cuse.clear(); }
+    if (H.cboxes.empty()) H.cboxes.assign(1, 0.f);
+    if (H.cuse.empty()) H.cuse.assign(1, 0u);
     H.refs.assign(d->node_ent_idx, d->node_ent_idx + d->node_ent_off[d->n_node]);
     H.tris.resize((size_t)d->n_tri);
     H.shade.resize((size_t)d->n_tri);

@@ -129,6 +129,11 @@ int gi_set_render_mode(gi_ctx*, int mode);
  * Exists so that the two can be compared.  Returns a bit set, negative on error: 1 = the wide walk is in use after the call
  * (a scene is uploaded and its tree qualifies), 2 = the uploaded photon octree is walked one record per level.               */
 int gi_set_wide_nodes(gi_ctx*, int enable);
+/* Content-box culling: 1 (default) = a child of the wide walk whose octant the ray enters is skipped when the ray misses the box of everything
+ * referenced in that child's sub-tree (no entity there can report a hit, so the walk's results are the same by construction); 0 = every such
+ * child is visited, as Octree::Node::intersectSorted does (include/octree.cpp:285-313).  Exists so that the two can be compared (frames are
+ * identical bit for bit).  Returns 1 when culling is in use after the call (a scene is uploaded, its tree takes the wide walk), else 0.      */
+int gi_set_content_culling(gi_ctx*, int enable);
 /* Upper bound on paths in flight in the wavefront pipeline (224 B each).  Default: as many as 80 % of the free HBM holds,
  * up to the whole frame (1080p x 256 spp = 531 M paths = 119 GB).                                                           */
 int gi_set_pool_slots(gi_ctx*, int64_t slots);

@@ -39,6 +39,7 @@ def lib():
         L.emul_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.emul_rng.restype = C.c_double
         L.emul_set_wide.argtypes = [vp, C.c_int]
+        L.emul_set_cull.argtypes = [vp, C.c_int]
         L.emul_leaf_order.argtypes = [vp, C.c_int, _dp, C.c_int, _ip, _ip]
         L.emul_kat.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp]
         _LIB = L
@@ -116,6 +117,9 @@ class EmulRayTracer(gi.RayTracer):
         rc = self.E.emul_set_wide(self.h, 1 if on else 0)
         self.photon_planes = bool(rc & 2)
         return bool(rc & 1)
+
+    def set_content_culling(self, on):
+        return bool(self.E.emul_set_cull(self.h, 1 if on else 0))
 
     def trace(self, rays):
         rays = gi._f64(rays).reshape(-1, 6); n = len(rays)

@@ -18,7 +18,7 @@ struct Emul {
     std::vector<uint16_t> htable;
     Scene S{};
     std::string err;
-    bool wide = true;
+    bool wide = true, cull = true;
     void bind()
     {
         S.tnodes = hs.tnodes.data(); S.leaf_refs = hs.refs.data(); S.leaf_tris = hs.leaf_tris.data(); S.tris = hs.tris.data(); S.shade = hs.shade.data();
@@ -28,6 +28,8 @@ struct Emul {
         S.n_wnode = (int32_t)hs.wnodes.size();
         S.wnodes = (wide && S.n_wnode > 0) ? hs.wnodes.data() : nullptr;
         S.wleaf_id = hs.wleaf_id.data();
+        S.cboxes = (cull && S.wnodes && hs.cboxes.size() > 1) ? hs.cboxes.data() : nullptr;
+        S.cuse = hs.cuse.data();
         S.tri_uv = hs.tri_uv.data(); S.texs = hs.texs.data(); S.tex_pixels = hs.tex_pixels.data(); S.tex_lut = hs.tex_lut.data(); S.n_tex = hs.n_tex();
         S.fogs = hs.fogs.data(); S.fog_grid = hs.fog_grid.data(); S.n_fog = hs.n_fog();
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];
@@ -43,6 +45,7 @@ extern "C" {
 Emul* emul_create() { Emul* e = new Emul(); build_halton_tables(e->hdims, e->htable); e->bind(); return e; }
 void emul_destroy(Emul* e) { delete e; }
 int emul_set_wide(Emul* e, int on) { e->wide = on != 0; e->bind(); return (e->S.wnodes != nullptr ? 1 : 0) | (e->S.pn_planes ? 2 : 0); }
+int emul_set_cull(Emul* e, int on) { e->cull = on != 0; e->bind(); return e->S.cboxes != nullptr ? 1 : 0; }
 const char* emul_error(Emul* e) { return e->err.c_str(); }
 int emul_upload_scene(Emul* e, const gi_scene_desc* d)
 {

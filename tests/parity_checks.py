@@ -257,6 +257,29 @@ def check_wide_walk(rt, scene, set_wide):
     assert np.array_equal(vis_w, vis_n)
 
 
+def check_content_culling(rt, scene, photons=2000, render=True):
+    """Content-box culling (a child of the walk is skipped when the ray misses the box of everything referenced below it) changes nothing:
+    hit flag, entity, hit point bits, visibility on the adversarial rays, and whole frames bit for bit, with and without."""
+    rays = adversarial_rays(scene)
+    rs = np.random.RandomState(9)
+    q = np.concatenate([rays[:, :3], rays[:, :3] + rays[:, 3:] * (rs.rand(len(rays), 1) * 12 + 0.01)], 1)
+    if not rt.set_content_culling(True):
+        return False                      # the tree does not take the wide walk: nothing to compare
+    a = rt.trace(rays); va = rt.visible(q)
+    assert not rt.set_content_culling(False)
+    b = rt.trace(rays); vb = rt.visible(q)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint64), b[2].view(np.uint64)) and np.array_equal(va, vb)
+    if render:
+        if scene.desc().n_light:
+            rt.tracePhotons(photons)
+        fb = rt.run(40, 30, min_samples=4, max_samples=4)
+        assert rt.set_content_culling(True)
+        fa = rt.run(40, 30, min_samples=4, max_samples=4)
+        assert np.array_equal(fa.view(np.uint64), fb.view(np.uint64))
+    rt.set_content_culling(True)
+    return True
+
+
 def check_photon_descent(rt, scene, photons=20000):
     """PhotonMap::getBounds walked one record per level (children's boxes from the parent's planes) and two records per level give
     identical gathers: inside, outside and on the faces of the map."""

@@ -55,6 +55,10 @@ def test_wide_walk_equals_per_node_walk(setup):
     pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
 
 
+def test_content_culling_changes_nothing(setup):
+    pc.check_content_culling(setup[2], setup[1], render=setup[0] in ("caustics", "spheres_opaque"))
+
+
 def test_photon_octree_descent_variants_agree():
     scene = pc.load_scene("caustics")
     pc.check_photon_descent(el.EmulRayTracer().setScene(scene), scene)

