@@ -1514,8 +1514,11 @@ GI_HD uint32_t coherence_key(const Scene& S, V3 o, V3 d)
 struct ShadeOut { uint32_t key; V3 gpos; };   // by-products of the shade stage for the queues: sort key of the next ray, position of the gather query
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
 template <int FEAT, class Nodes>
-GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr)
+// Lext: where the path's radiance accumulates when it does not live in the record (streaming pipeline: the per-sample radiance buffer,
+// so that a path that ends -- 96 % of the benchmark's reflected rays leave the scene -- has nothing left to read or write); else p.L
+GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr, double* Lext = nullptr)
 {
+    double* const Lp = Lext ? Lext : p.L;
     Rng rng = rng_make(seed, p.stream);
     const int depth = p.depth;
     rng.depth = (uint32_t)depth;
@@ -1588,7 +1591,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
 #if !defined(GI_EXP_SHADE) || GI_EXP_SHADE < 3
     p.contrib[0] = contrib.x; p.contrib[1] = contrib.y; p.contrib[2] = contrib.z;
 #endif
-    V3 T = depth == 0 ? v3(1, 1, 1) : ld3(p.T), L = depth == 0 ? v3(0, 0, 0) : ld3(p.L);
+    V3 T = depth == 0 ? v3(1, 1, 1) : ld3(p.T), L = depth == 0 ? v3(0, 0, 0) : ld3(Lp);
     double q = comp_max(contrib);
     if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
         f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
@@ -1597,7 +1600,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         if (L.x == 1.2345e300) p.L[0] = L.x + refDir.x + contrib.x + f.x;   // keeps the arithmetic alive, stores nothing
         return ST_CONTINUE | ST_GATHER;
 #endif
-        p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+        Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
         int flags = 0;
         if (depth <= 10 && S.n_pnode > 0) {   // caustic = depth <= 10 ? samplePhotons(minHit, refDir, 32) : 0, include/raytracer.h:258
             V3 gc = T * color;
@@ -1616,7 +1619,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         return flags;
     }
     L = L + T * (color * i);
-    p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+    Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
     return 0;
 }
 GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
@@ -1631,11 +1634,12 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     return S.n_tex > 0 ? stage_shade_nodes<7>(S, N, p, seed, c) : stage_shade_nodes<3>(S, N, p, seed, c);
 }
 // stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
-GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride)
+GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride, double* Lext = nullptr)
 {
+    double* const Lp = Lext ? Lext : p.L;
     V3 caustic = gather_in_leaf(S, leaf, ld3(p.hpos), ld3(p.gdir), heap_mem, heap_stride, nullptr, nullptr);
-    V3 L = ld3(p.L) + ld3(p.gcoef) * caustic;
-    p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+    V3 L = ld3(Lp) + ld3(p.gcoef) * caustic;
+    Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
 }
 GI_HD void stage_gather(const Scene& S, PathRec& p, float* heap_mem, int heap_stride, Counters* c)
 {

@@ -419,13 +419,9 @@ __host__ __device__ __forceinline__ uint32_t seg_start(uint32_t b, uint32_t n_in
     return (lo * (full + 1) + (b - lo) * full) * bs;
 }
 
-__device__ __forceinline__ void st_finish(const PathRec& p, uint32_t slot, const unsigned long long* slot_sample, unsigned long long sample0,
-                                          double* lbuf, uint32_t* q_free, unsigned int* n_free, bool finished)
+// a finished path gives its slot back (its radiance is already in the per-sample buffer: the stages accumulate there)
+__device__ __forceinline__ void st_release(uint32_t slot, uint32_t* q_free, unsigned int* n_free, bool finished)
 {
-    if (finished) {
-        const unsigned long long id = slot_sample[slot] - sample0;
-        lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
-    }
     const uint32_t at = wave_append(n_free, finished);
     if (finished) q_free[at] = slot;
 }
@@ -493,14 +489,22 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                 p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
                 p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.pad = h.mf;
                 if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
-            } else {
-                // the path ends here: a miss adds T * ambient (stage_trace_nodes), past MAX_DEPTH nothing; L goes straight to the radiance buffer
-                const bool first = depth == 0;   // L = 0, T = 1 by definition (PathRec)
-                V3 L = first ? v3(0, 0, 0) : ld3(p.L);
-                if (depth <= GI_MAX_DEPTH) L = L + (first ? v3(1, 1, 1) : ld3(p.T)) * ld3(S.ambient);
-                if (!gen) id = slot_sample[slot];
-                double* o = lbuf + (id - sample0) * 3;
-                o[0] = L.x; o[1] = L.y; o[2] = L.z;
+            } else if (depth <= GI_MAX_DEPTH) {
+                // the path ends here with a miss: L += T * ambient (stage_trace_nodes), on the per-sample radiance buffer where the path's L lives.
+                // A path at depth 0 writes (L = 0, T = 1 by definition); a deeper one adds -- and when the scene has no ambient light there is nothing
+                // to add (L + T * 0 = L: L is a sum of non-negative terms and photon terms, never -0), so the record's tail, the sample id and
+                // the buffer are not touched at all: this is what 96 % of the benchmark's reflected rays do.
+                const V3 amb = ld3(S.ambient);
+                if (depth == 0) {   // generated here, or handed in by the adaptive loop's generator (k_ad_gen)
+                    const V3 L = v3(0, 0, 0) + v3(1, 1, 1) * amb;
+                    if (!gen) id = slot_sample[slot];
+                    double* o = lbuf + (id - sample0) * 3;
+                    o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                } else if (amb.x != 0.0 || amb.y != 0.0 || amb.z != 0.0) {
+                    double* o = lbuf + (slot_sample[slot] - sample0) * 3;
+                    const V3 L = ld3(o) + ld3(p.T) * amb;
+                    o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                }
             }
         }
         const uint32_t at = wave_append(c_shade, hit);
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
 #if GI_EXP_SHADE >= 5   // measurement aids (never defined in the product build): bisecting the cost of the shade stage
             fl = ST_CONTINUE | ST_GATHER;
 #else
-            fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr, &so);
+            fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr, &so, lbuf + (slot_sample[slot] - sample0) * 3);
 #endif
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
             g_pos[(size_t)(seg + g) * 3] = so.gpos.x; g_pos[(size_t)(seg + g) * 3 + 1] = so.gpos.y; g_pos[(size_t)(seg + g) * 3 + 2] = so.gpos.z;
 #endif
         }
-        st_finish(pool[slot], slot, slot_sample, sample0, lbuf, q_free + seg, c_free, valid && !cont);
+        st_release(slot, q_free + seg, c_free, valid && !cont);
     }
 }
 
@@ -670,7 +674,8 @@ __device__ __forceinline__ void kmerge32(float (&v)[32])   // bitonic sequence -
             if (l > i) kce(v[i], v[l]);
         }
 }
-__global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in)
+__global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in,
+                                                                         const unsigned long long* slot_sample, unsigned long long sample0, double* lbuf)
 {
     // 8 KB of LDS per wave: the staged candidates of the cooperative path (64 x 9 doubles) or the float heaps of the per-lane walk (32 x 64),
     // never both at once -- a wave is in one of the two, and the tie pass runs after the last candidate was read
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
         const bool has_leaf = valid && leaf < (uint32_t)S.n_pnode;
         const bool uniform = __ballot(valid && leaf != leaf0) == 0ull && leaf0 < (uint32_t)S.n_pnode;
         if (!uniform) {
-            if (has_leaf) stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap, 64);
+            if (has_leaf) stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap, 64, lbuf + (slot_sample[vals[i]] - sample0) * 3);
             continue;
         }
         const PNode& lf = S.pnodes[leaf0];
@@ -755,8 +760,9 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
         if (valid) {
             V3 caustic;
             if (!g_end(a, caustic)) caustic = gather_in_leaf(S, (int32_t)leaf0, a.pos, a.dir, heap, 64, nullptr, nullptr);   // float-key tie: exact pass
-            V3 L = ld3(p->L) + ld3(p->gcoef) * caustic;
-            p->L[0] = L.x; p->L[1] = L.y; p->L[2] = L.z;
+            double* Lp = lbuf + (slot_sample[vals[i]] - sample0) * 3;   // the path's radiance lives in the per-sample buffer
+            V3 L = ld3(Lp) + ld3(p->gcoef) * caustic;
+            Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
         }
     }
 }
@@ -786,6 +792,8 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
             for (uint32_t i = wave; i < n_in; i += n_waves) {
                 const uint32_t slot = q_in[i];
                 PathRec p = pool[slot];
+                double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance so far; kept in registers while this stage works on it
+                p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
                 bool alive = true;
                 for (int b = 0;;) {
                     if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; break; }
@@ -795,12 +803,10 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
                     if (++b >= max_bounces) break;
                 }
                 if (lane == 0) {
+                    Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
                     if (alive) {
                         pool[slot] = p;
                         q_out[atomicAdd(n_out, 1u)] = slot;
-                    } else {
-                        const unsigned long long id = slot_sample[slot] - sample0;
-                        lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
                     }
                 }
             }
@@ -812,6 +818,8 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
     for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
         const uint32_t slot = q_in[i];
         PathRec p = pool[slot];
+        double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;
+        p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
         bool alive = true;
         for (int b = 0;;) {
             if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; break; }
@@ -820,12 +828,10 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
             if (!(fl & ST_CONTINUE)) { alive = false; break; }
             if (++b >= max_bounces) break;
         }
+        Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
         if (alive) {
             pool[slot] = p;
             q_out[atomicAdd(n_out, 1u)] = slot;
-        } else {
-            const unsigned long long id = slot_sample[slot] - sample0;
-            lbuf[id * 3] = p.L[0]; lbuf[id * 3 + 1] = p.L[1]; lbuf[id * 3 + 2] = p.L[2];
         }
     }
 }
@@ -1016,6 +1022,7 @@ struct gi_ctx {
     DevBuf<float> d_cboxes;           // content boxes of the wide records' children
     DevBuf<uint32_t> d_cuse;
     bool cull_enabled = true;         // gi_set_content_culling
+    bool sort_cont = true;            // GI_SORT_CONT=0: continuing rays stay in queue order
     bool wide_enabled = true;         // gi_set_wide_nodes
     bool pn_planes_ok = false;        // the uploaded photon octree qualifies for the one-record-per-level descent
     int32_t n_prange = 0;             // entries of d_pranges in use
@@ -1118,6 +1125,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     c->S.htable = c->d_htable.p;
     if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
+    if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
     if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."
         std::vector<std::pair<int, int>> plan;
@@ -1474,7 +1482,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             stage_begin(c, STG_SORT);
             HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
             stage_end(c);
-            stage_begin(c, STG_GATHER); hipLaunchKernelGGL(k_st_gather, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather); stage_end(c);
+            stage_begin(c, STG_GATHER); hipLaunchKernelGGL(k_st_gather, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf); stage_end(c);
             launches += 2;
         }
         n_cont = c->h_ctl->n_cont;
@@ -1482,7 +1490,8 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
             size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
-            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, 0, 27, st));
+            if (c->sort_cont) HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, 0, 27, st));
+            else HIP_TRY(c, hipMemcpyAsync(qcont_out, c->d_cv.p, (size_t)n_cont * 4, hipMemcpyDeviceToDevice, st));   // GI_SORT_CONT=0: queue order (tuning aid)
             stage_end(c);
             launches++;
         }
