@@ -678,12 +678,25 @@ GI_HD void wide_leaf_box(const WNode* w, int slot, double* lmin, double* lmax)  
         else { lmin[ax] = w->pl[ax][bit[ax] * 2]; lmax[ax] = w->pl[ax][bit[ax] * 2 + 1]; }
     }
 }
+
+// measurement aid (never defined in the product build): lane-level and wave-level step counts of the wide walk, to tell how much of a
+// wave's work is lanes waiting for the slowest ray (tools/divergence_probe.py)
+#if defined(GI_EXP_DIV) && defined(__HIP_DEVICE_COMPILE__)
+#define GI_DIV(W, k) do { (W).ds[(k)]++; if ((uint32_t)__builtin_ctzll(__ballot(1)) == (threadIdx.x & 63u)) (W).ds[(k) + 1]++; } while (0)
+#define GI_DIVN(W, k, n) do { (W).ds[(k)] += (n); if ((uint32_t)__builtin_ctzll(__ballot(1)) == (threadIdx.x & 63u)) (W).ds[(k) + 1] += (n); } while (0)
+#else
+#define GI_DIV(W, k) do { } while (0)
+#define GI_DIVN(W, k, n) do { } while (0)
+#endif
 struct GlobalWide {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
     const WNode* g;
     const float* cboxes = nullptr;      // content boxes (null: the walk visits every child whose octant the ray enters)
     const uint32_t* cuse = nullptr;
+#ifdef GI_EXP_DIV
+    mutable uint32_t ds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     template <class F> GI_HDM auto with(int32_t i, F&& f) const { return f(g + i); }
 };
 // walk state: the node, the children of it still to visit (bit k = k-th in order), and the same masks of its ancestors, one
@@ -713,6 +726,7 @@ GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr
         int32_t ca = 0, cb = 0;
         W.with(k.node, [&](const WNode* w) { ca = w->ca[slot]; cb = w->cb[slot]; return 0; });
         if (cb < 0) {
+            GI_DIV(W, 0);
             wwalk_push(k, ca);
             k.m = W.with(ca, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
             if (W.cboxes && k.m) k.m = content_cull(W.cboxes, W.cuse, ca, k.m, ray, wr);
@@ -731,61 +745,75 @@ GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, co
     if (W.cboxes && k.m) k.m = content_cull(W.cboxes, W.cuse, 0, k.m, ray, wr);
     return true;
 }
+// RayTracer::trace over the wide records, one leaf per call: the streaming trace kernel keeps a wave's lanes on different rays and hands a
+// finished lane its next ray while the others walk on (k_st_trace), everybody else runs the loop in trace_wide.
+struct TraceWalk {
+    WRay wr;
+    WWalk k;
+    bool intersected;
+    double best_d2;
+    double cu, cv;   // the reference's `glm::dvec2 uv` of trace(): written by every successful intersect of a smooth triangle or sphere
+};
+template <int FEAT, class WN>
+GI_HD bool trace_wide_begin(const Scene& S, const WN& W, const Ray& ray, TraceWalk& t)   // false: the ray misses the scene's box
+{
+    t.wr = wray_make(ray);
+    t.intersected = false;
+    t.best_d2 = 0; t.cu = 0; t.cv = 0;
+    return wwalk_begin(S, W, t.k, ray, t.wr, 0.0, INFINITY);
+}
+template <int FEAT, class WN>
+GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, TraceWalk& t, HitRec& best)   // false: the walk is over
+{
+    int32_t lnode = 0, first = 0, cnt = 0;
+    int lslot = 0;
+    if (!wwalk_next_leaf(W, t.k, ray, t.wr, 0.0, INFINITY, lnode, lslot, first, cnt)) return false;
+    GI_DIV(W, 2);
+    bool term = false;
+    auto test = [&](const LeafTri& g) {
+        const int32_t ti = g.tri;
+        double u, v;
+        V3 hp;
+        if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return;
+        if (FEAT & GI_FEAT_TEX) ent_uv(S, g, g.matflags, ti, u, v, hp, t.cu, t.cv);
+        if (!(g.matflags & 2u)) {
+            const Mat& m = S.mats[g.matflags >> 3];
+            const double alpha = (FEAT & GI_FEAT_TEX) ? mat_alpha(S, m, t.cu, t.cv) : m.opacity * 1.0;
+            if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return;
+        }
+        double d2 = len2(hp - ray.o);
+        if (!t.intersected || d2 < t.best_d2) {
+            best.pos = hp; best.u = u; best.v = v; best.tri = ti; best.mf = g.matflags;
+            if (FEAT & GI_FEAT_TEX) { best.tu = t.cu; best.tv = t.cv; }
+            t.best_d2 = d2;
+            t.intersected = true;
+            double lmin[3], lmax[3];
+            W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
+            if (box_contains(lmin, lmax, hp)) term = true;
+        }
+    };
+#ifdef GI_WAVE_UNIFORM_LEAVES
+    int32_t first_u, cnt_u;
+    if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
+        for (int32_t j = 0; j < cnt_u; j++) { GI_DIV(W, 4); test(leaf_tri_scalar(S.leaf_tris + first_u + j)); }
+    } else
+#endif
+    for (int32_t j = 0; j < cnt; j += 2) {
+        const LeafTri g0 = S.leaf_tris[first + j];
+        const LeafTri g1 = S.leaf_tris[first + (j + 1 < cnt ? j + 1 : j)];
+        GI_DIV(W, 6);
+        test(g0);
+        if (j + 1 < cnt) { GI_DIV(W, 6); test(g1); }
+    }
+    return !term;
+}
 template <int FEAT, class WN>
 GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best)
 {
-    const WRay wr = wray_make(ray);
-    bool intersected = false;
-    double best_d2 = 0;
-    double cu = 0, cv = 0;   // the reference's `glm::dvec2 uv` of trace(): written by every successful intersect of a smooth triangle or sphere
-    WWalk k;
-    if (!wwalk_begin(S, W, k, ray, wr, 0.0, INFINITY)) return false;
-    for (;;) {
-        int32_t lnode = 0, first = 0, cnt = 0;
-        int lslot = 0;
-        if (!wwalk_next_leaf(W, k, ray, wr, 0.0, INFINITY, lnode, lslot, first, cnt)) break;
-        bool term = false;
-        auto test = [&](const LeafTri& g) {
-            const int32_t ti = g.tri;
-            double u, v;
-            V3 hp;
-            if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return;
-            if (FEAT & GI_FEAT_TEX) ent_uv(S, g, g.matflags, ti, u, v, hp, cu, cv);
-            if (!(g.matflags & 2u)) {
-                const Mat& m = S.mats[g.matflags >> 3];
-                const double alpha = (FEAT & GI_FEAT_TEX) ? mat_alpha(S, m, cu, cv) : m.opacity * 1.0;
-                if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return;
-            }
-            double d2 = len2(hp - ray.o);
-            if (!intersected || d2 < best_d2) {
-                best.pos = hp; best.u = u; best.v = v; best.tri = ti; best.mf = g.matflags;
-                if (FEAT & GI_FEAT_TEX) { best.tu = cu; best.tv = cv; }
-                best_d2 = d2;
-                intersected = true;
-                double lmin[3], lmax[3];
-                W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
-                if (box_contains(lmin, lmax, hp)) term = true;
-            }
-        };
-#ifdef GI_WAVE_UNIFORM_LEAVES
-        int32_t first_u, cnt_u;
-        if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
-            for (int32_t j = 0; j < cnt_u; j++) test(leaf_tri_scalar(S.leaf_tris + first_u + j));
-        } else
-#endif
-#ifdef GI_EXP_ONE_TRI
-        for (int32_t j = 0; j < cnt; j++) test(S.leaf_tris[first + j]);
-#else
-        for (int32_t j = 0; j < cnt; j += 2) {
-            const LeafTri g0 = S.leaf_tris[first + j];
-            const LeafTri g1 = S.leaf_tris[first + (j + 1 < cnt ? j + 1 : j)];
-            test(g0);
-            if (j + 1 < cnt) test(g1);
-        }
-#endif
-        if (term) break;
-    }
-    return intersected;
+    TraceWalk t;
+    if (!trace_wide_begin<FEAT>(S, W, ray, t)) return false;
+    while (trace_wide_step<FEAT>(S, W, ray, rng, alpha_purpose, t, best)) { }
+    return t.intersected;
 }
 template <int FEAT, class WN>
 GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index)
@@ -799,6 +827,7 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
             int32_t lnode = 0, first = 0, cnt = 0;
             int lslot = 0;
             if (!wwalk_next_leaf(W, k, ray, wr, 0.0, tmax, lnode, lslot, first, cnt)) break;
+            GI_DIV(W, 2);
             auto blocks = [&](const LeafTri& g) -> bool {
                 const int32_t ti = g.tri;
                 double u, v;
@@ -819,6 +848,7 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
                 bool hit = false;
                 for (int32_t j = 0; j < cnt_u; j++) {     // wave-uniform trip count: the record address stays scalar
                     const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
+                    GI_DIV(W, 4);
                     if (!hit) hit = blocks(g);
                     if (__ballot(!hit) == 0ull) break;
                 }
@@ -826,8 +856,10 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
                 continue;
             }
 #endif
-            for (int32_t j = 0; j < cnt; j++)
+            for (int32_t j = 0; j < cnt; j++) {
+                GI_DIV(W, 6);
                 if (blocks(S.leaf_tris[first + j])) return false;
+            }
         }
     }
     if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:308-316

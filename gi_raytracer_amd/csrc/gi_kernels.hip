@@ -126,12 +126,38 @@ struct LdsWide {
     const float* cboxes;      // content boxes of the children (gi_device.h: content_cull), read through L1 / L2; null = no culling
     const uint32_t* cuse;
     int32_t n_l;
+#ifdef GI_EXP_DIV
+    mutable uint32_t ds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lane / wave counts of: node steps, leaves, triangle tests (scalar path), triangle tests (per-lane path)
+#endif
     template <class F> __device__ __forceinline__ auto with(int32_t i, F&& f) const
     {
         if (i < n_l) return f(reinterpret_cast<const WNode*>(gi_dyn_lds) + i);
         return f(g + i);
     }
 };
+#ifdef GI_EXP_DIV
+__device__ unsigned long long g_div[64 * 16 * 2];   // [workgroup & 63][kernel][counter]
+__device__ __forceinline__ void div_flush(const LdsWide& N, int kernel)
+{
+    for (int k = 0; k < 8; k++) {
+        unsigned long long v = N.ds[k];
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&g_div[((blockIdx.x & 63u) * 2 + kernel) * 16 + k], v);
+    }
+    unsigned long long one = 1;
+    for (int o = 32; o; o >>= 1) one += __shfl_xor(one, o);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_div[((blockIdx.x & 63u) * 2 + kernel) * 16 + 8], one);
+}
+extern "C" int gi_debug_div(unsigned long long* out, int reset)
+{
+    static unsigned long long h[64 * 16 * 2];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_div), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 32; i++) out[i] = 0;
+    for (int b = 0; b < 64; b++) for (int i = 0; i < 32; i++) out[i] += h[b * 32 + i];
+    if (reset) { static unsigned long long z[64 * 16 * 2]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_div), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; };   // the same records, one ray per wave (gi_device.h: trace_wide_coop)
 __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S)
 {
@@ -439,79 +465,151 @@ struct GenArgs {
     unsigned long long id_base, sample_begin;
     int s_begin;
 };
+// Wide-record instances keep the lanes of a wave on DIFFERENT rays: a lane whose walk is over waits until `refill_min` lanes of its wave
+// are idle, then the idle lanes write their results and take the next items of the workgroup's share of the queue (an LDS counter), while
+// the others walk on -- a wave no longer runs at the pace of its longest ray with the other lanes switched off (closed scenes: a third
+// of the lanes were active per leaf step).  Waves of new paths (neighbouring pixels, leaves shared through the scalar cache) stay in
+// lockstep: refill_min = 64 for them.  The workgroup's items are those of the grid-stride loop, so seg_start still bounds its output.
 template <int FEAT, int WIDE>
 __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, unsigned long long* slot_sample, unsigned long long sample0,
                                                        GenArgs g, const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, unsigned int* bc, uint32_t* segs,
-                                                       uint32_t* q_shade, uint32_t* q_free, double* lbuf)
+                                                       uint32_t* q_shade, uint32_t* q_free, double* lbuf, uint32_t refill_min)
 {
-    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);
+    // wide instances: next unfetched item of this workgroup, in its own numbering; lives in the 128 bytes the 292 wide records leave of the 64 KB
+    static_assert((size_t)GI_LDS_WNODES * sizeof(WNode) + sizeof(unsigned int) <= (size_t)GI_LDS_NODES * sizeof(TNode), "no room for the fetch counter");
+    unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
+    if (WIDE != 0 && threadIdx.x == 0) *s_next = 0u;
+    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = g.n_gen + n_a + n_b;
     const uint32_t seg = seg_start(blockIdx.x, n_in, gridDim.x, blockDim.x);   // this workgroup's segment of the staging queues
     if (threadIdx.x == 0) segs[blockIdx.x] = seg;
     unsigned int* const c_shade = blk_counter(bc, QC_SHADE);
     unsigned int* const c_free = blk_counter(bc, QC_FREE);
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
-        const uint32_t i = i0 + lane;
-        bool hit = false, fin = false;
-        uint32_t slot = 0;
-        if (i < n_in) {
-            const bool gen = i < g.n_gen;
-            Ray ray;
-            uint32_t stream;
-            int32_t depth = 0;
-            unsigned long long id = 0;
-            if (gen) {
-                slot = g.q_free ? g.q_free[i] : i;
-                id = g.id_base + i;
-                // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
-                const uint32_t rel = (uint32_t)(id - g.sample_begin), srel = rel / g.n_pix;
-                int x, ly;
-                st_pixel_xy(g.F, rel - srel * g.n_pix, x, ly);
-                ray = primary_ray(S, g.F, g.s_begin + (int)srel, x, global_row(g.F, ly), stream);
-            } else {
-                slot = i - g.n_gen < n_a ? q_a[i - g.n_gen] : q_b[i - g.n_gen - n_a];
-                const PathRec& p = pool[slot];
-                ray = make_ray_exact(ld3(p.o), ld3(p.d));
-                stream = p.stream; depth = p.depth;
-            }
-            HitRec h;
-            if (depth > GI_MAX_DEPTH) fin = true;            // radiance() returns 0 past MAX_DEPTH
-            else {
-                Rng rng = rng_make(seed, stream);
-                rng.depth = (uint32_t)depth;
-                hit = trace_nodes<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, h, nullptr);
-                fin = !hit;
-            }
-            PathRec& p = pool[slot];
-            if (hit) {
-                if (gen) { path_begin_lean(p, ray, stream); slot_sample[slot] = id; }
-                p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
-                p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.pad = h.mf;
-                if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
-            } else if (depth <= GI_MAX_DEPTH) {
-                // the path ends here with a miss: L += T * ambient (stage_trace_nodes), on the per-sample radiance buffer where the path's L lives.
-                // A path at depth 0 writes (L = 0, T = 1 by definition); a deeper one adds -- and when the scene has no ambient light there is nothing
-                // to add (L + T * 0 = L: L is a sum of non-negative terms and photon terms, never -0), so the record's tail, the sample id and
-                // the buffer are not touched at all: this is what 96 % of the benchmark's reflected rays do.
-                const V3 amb = ld3(S.ambient);
-                if (depth == 0) {   // generated here, or handed in by the adaptive loop's generator (k_ad_gen)
-                    const V3 L = v3(0, 0, 0) + v3(1, 1, 1) * amb;
-                    if (!gen) id = slot_sample[slot];
-                    double* o = lbuf + (id - sample0) * 3;
-                    o[0] = L.x; o[1] = L.y; o[2] = L.z;
-                } else if (amb.x != 0.0 || amb.y != 0.0 || amb.z != 0.0) {
-                    double* o = lbuf + (slot_sample[slot] - sample0) * 3;
-                    const V3 L = ld3(o) + ld3(p.T) * amb;
-                    o[0] = L.x; o[1] = L.y; o[2] = L.z;
-                }
+    // one item: a new path (sample id -> primary ray) or a continuing one (ray from its record)
+    auto fetch = [&](uint32_t i, uint32_t& slot, Ray& ray, uint32_t& stream, int32_t& depth) {
+        if (i < g.n_gen) {
+            slot = g.q_free ? g.q_free[i] : i;
+            const unsigned long long id = g.id_base + i;
+            // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
+            const uint32_t rel = (uint32_t)(id - g.sample_begin), srel = rel / g.n_pix;
+            int x, ly;
+            st_pixel_xy(g.F, rel - srel * g.n_pix, x, ly);
+            ray = primary_ray(S, g.F, g.s_begin + (int)srel, x, global_row(g.F, ly), stream);
+            depth = 0;
+        } else {
+            slot = i - g.n_gen < n_a ? q_a[i - g.n_gen] : q_b[i - g.n_gen - n_a];
+            const PathRec& p = pool[slot];
+            ray = make_ray_exact(ld3(p.o), ld3(p.d));
+            stream = p.stream; depth = p.depth;
+        }
+    };
+    // what a finished walk leaves behind: the hit in the record (a new path's record is created here), or the end of the path
+    auto retire = [&](uint32_t i, uint32_t slot, const Ray& ray, uint32_t stream, int32_t depth, bool hit, const HitRec& h) {
+        const bool gen = i < g.n_gen;
+        PathRec& p = pool[slot];
+        if (hit) {
+            if (gen) { path_begin_lean(p, ray, stream); slot_sample[slot] = g.id_base + i; }
+            p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
+            p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.pad = h.mf;
+            if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
+        } else if (depth <= GI_MAX_DEPTH) {
+            // the path ends here with a miss: L += T * ambient (stage_trace_nodes), on the per-sample radiance buffer where the path's L lives.
+            // A path at depth 0 writes (L = 0, T = 1 by definition); a deeper one adds -- and when the scene has no ambient light there is nothing
+            // to add (L + T * 0 = L: L is a sum of non-negative terms and photon terms, never -0), so the record's tail, the sample id and
+            // the buffer are not touched at all: this is what 96 % of the benchmark's reflected rays do.
+            const V3 amb = ld3(S.ambient);
+            if (depth == 0) {   // generated here, or handed in by the adaptive loop's generator (k_ad_gen)
+                const V3 L = v3(0, 0, 0) + v3(1, 1, 1) * amb;
+                const unsigned long long id = gen ? g.id_base + i : slot_sample[slot];
+                double* o = lbuf + (id - sample0) * 3;
+                o[0] = L.x; o[1] = L.y; o[2] = L.z;
+            } else if (amb.x != 0.0 || amb.y != 0.0 || amb.z != 0.0) {
+                double* o = lbuf + (slot_sample[slot] - sample0) * 3;
+                const V3 L = ld3(o) + ld3(p.T) * amb;
+                o[0] = L.x; o[1] = L.y; o[2] = L.z;
             }
         }
-        const uint32_t at = wave_append(c_shade, hit);
-        if (hit) q_shade[seg + at] = slot;
-        const uint32_t af = wave_append(c_free, fin);
-        if (fin) q_free[seg + af] = slot;
+    };
+    if constexpr (WIDE != 0) {
+        const uint32_t bs = blockDim.x;
+        const uint32_t total = seg_start(blockIdx.x + 1, n_in, gridDim.x, bs) - seg;   // this workgroup's chunks, counted as full
+        bool walking = false, pend = false;
+        uint32_t item = 0, slot = 0, stream = 0;
+        int32_t depth = 0;
+        Ray ray = make_ray_exact(v3(0, 0, 0), v3(1, 0, 0));
+        Rng rng = rng_make(seed, 0);
+        TraceWalk t;
+        t.intersected = false;
+        HitRec h;
+        bool more = true;            // wave-uniform: the workgroup may still have items
+        uint32_t thr = 64u;          // wave-uniform: idle lanes that trigger a refill
+        for (;;) {
+            const unsigned long long busy = __ballot(walking);
+            if (busy == 0ull || (more && 64u - (uint32_t)__popcll(busy) >= thr)) {
+                const bool hit = pend && t.intersected, fin = pend && !t.intersected;
+                if (pend) retire(item, slot, ray, stream, depth, hit, h);
+                const uint32_t at = wave_append(c_shade, hit);
+                if (hit) q_shade[seg + at] = slot;
+                const uint32_t af = wave_append(c_free, fin);
+                if (fin) q_free[seg + af] = slot;
+                pend = false;
+                if (more) {
+                    const unsigned long long want = ~busy;
+                    const uint32_t nw = (uint32_t)__popcll(want);
+                    unsigned int base = 0;
+                    if (lane == (uint32_t)(__ffsll((long long)want) - 1)) base = atomicAdd(s_next, nw);
+                    base = (unsigned int)__shfl((int)base, __ffsll((long long)want) - 1);
+                    more = base + nw < total;
+                    // first item this fetch hands out: new paths run in lockstep, continuing ones refill
+                    const uint32_t i_first = ((base / bs) * gridDim.x + blockIdx.x) * bs + base % bs;
+                    thr = i_first < g.n_gen ? 64u : refill_min;
+                    if (!walking) {
+                        const uint32_t u = base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                        const uint32_t i = ((u / bs) * gridDim.x + blockIdx.x) * bs + u % bs;
+                        if (u < total && i < n_in) {
+                            item = i;
+                            fetch(i, slot, ray, stream, depth);
+                            rng = rng_make(seed, stream);
+                            rng.depth = (uint32_t)depth;
+                            t.intersected = false;
+                            pend = true;          // over already (past MAX_DEPTH radiance() returns 0; a ray that misses the scene's box) unless the walk starts
+                            if (depth <= GI_MAX_DEPTH && trace_wide_begin<FEAT>(S, N, ray, t)) { walking = true; pend = false; }
+                        }
+                    }
+                }
+                if (__ballot(walking || pend) == 0ull) break;
+            }
+            if (walking && !trace_wide_step<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, t, h)) { walking = false; pend = true; }
+        }
+    } else {
+        for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
+            const uint32_t i = i0 + lane;
+            bool hit = false, fin = false;
+            uint32_t slot = 0;
+            if (i < n_in) {
+                Ray ray;
+                uint32_t stream;
+                int32_t depth = 0;
+                fetch(i, slot, ray, stream, depth);
+                HitRec h;
+                if (depth <= GI_MAX_DEPTH) {            // radiance() returns 0 past MAX_DEPTH
+                    Rng rng = rng_make(seed, stream);
+                    rng.depth = (uint32_t)depth;
+                    hit = trace_nodes<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, h, nullptr);
+                }
+                fin = !hit;
+                retire(i, slot, ray, stream, depth, hit, h);
+            }
+            const uint32_t at = wave_append(c_shade, hit);
+            if (hit) q_shade[seg + at] = slot;
+            const uint32_t af = wave_append(c_free, fin);
+            if (fin) q_free[seg + af] = slot;
+        }
     }
+#ifdef GI_EXP_DIV
+    if constexpr (WIDE != 0) div_flush(N, 0);
+#endif
 }
 
 template <int FEAT, int WIDE>
@@ -519,7 +617,11 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
                                                        const uint32_t* q_shade, const StreamCtl* ctl, unsigned int* bc, uint32_t* segs, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, double* g_pos,
                                                        uint32_t* q_free, double* lbuf)
 {
-    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);
+    // the waves of a workgroup take its items 64 at a time from a counter in LDS (in the 128 bytes the wide records leave free) instead of
+    // a fixed share each: a wave that drew cheap items takes more of them
+    unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
+    if (WIDE != 0 && threadIdx.x == 0) *s_next = 0u;
+    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // ends with a barrier
     const uint32_t n_in = ctl->n_shade;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t seg = seg_start(blockIdx.x, n_in, gridDim.x, blockDim.x);   // this workgroup's segment of the staging queues (k_st_trace)
@@ -527,8 +629,16 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
     unsigned int* const c_cont = blk_counter(bc, QC_CONT);
     unsigned int* const c_gather = blk_counter(bc, QC_GATHER);
     unsigned int* const c_free = blk_counter(bc, QC_FREE);
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
-        const uint32_t i = i0 + lane;
+    const uint32_t total = seg_start(blockIdx.x + 1, n_in, gridDim.x, blockDim.x) - seg;   // this workgroup's chunks of the grid-stride loop, counted as full
+    for (uint32_t w = threadIdx.x >> 6;; w += blockDim.x >> 6) {
+        uint32_t u = w * 64u;
+        if (WIDE != 0) {
+            unsigned int b = 0;
+            if (lane == 0) b = atomicAdd(s_next, 64u);
+            u = (uint32_t)__shfl((int)b, 0);
+        }
+        if (u >= total) break;
+        const uint32_t i = ((u / blockDim.x) * gridDim.x + blockIdx.x) * blockDim.x + u % blockDim.x + lane;
         int fl = 0;
         bool valid = i < n_in;
         uint32_t slot = 0;
@@ -567,6 +677,9 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
         }
         st_release(slot, q_free + seg, c_free, valid && !cont);
     }
+#ifdef GI_EXP_DIV
+    if constexpr (WIDE != 0) div_flush(N, 1);
+#endif
 }
 
 // Closes the gaps between the workgroups' segments of up to three staging queues (one launch per producer kernel).  Stream k copies
@@ -1023,6 +1136,7 @@ struct gi_ctx {
     DevBuf<uint32_t> d_cuse;
     bool cull_enabled = true;         // gi_set_content_culling
     bool sort_cont = true;            // GI_SORT_CONT=0: continuing rays stay in queue order
+    uint32_t refill_min = 32;         // GI_REFILL_MIN: idle lanes of a wave that make k_st_trace hand out new rays (64: lockstep waves)
     bool wide_enabled = true;         // gi_set_wide_nodes
     bool pn_planes_ok = false;        // the uploaded photon octree qualifies for the one-record-per-level descent
     int32_t n_prange = 0;             // entries of d_pranges in use
@@ -1126,6 +1240,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
+    if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
     if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."
         std::vector<std::pair<int, int>> plan;
@@ -1444,7 +1559,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         // trace: hits -> staging 0, finished paths -> staging 1; compacted into the shade queue and the head of the free list
         HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
         stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, bc, c->d_segs.p,
-                           c->d_stage[0].p, c->d_stage[1].p, lbuf); stage_end(c);
+                           c->d_stage[0].p, c->d_stage[1].p, lbuf, c->refill_min); stage_end(c);
         {
             CompactJob job;
             memset(&job, 0, sizeof job);

@@ -1,7 +1,8 @@
 """Time one rank's share of the default frame for several world sizes on ONE GPU (predicts strong scaling)."""
-import sys, json
+import os, sys, json
 import numpy as np
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gi_raytracer_amd as gi
 scene = gi.Scene.load("scenes/caustics/caustics.scn").rebuild()
 rt = gi.RayTracer(0).setScene(scene)
