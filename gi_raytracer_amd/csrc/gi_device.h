@@ -815,54 +815,66 @@ GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rn
     while (trace_wide_step<FEAT>(S, W, ray, rng, alpha_purpose, t, best)) { }
     return t.intersected;
 }
-template <int FEAT, class WN>
-GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index)
-{
-    WRay wr = wray_make(ray);
-    const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
-    wr.tc = sqrt(mt) * (1.0 + 1e-9);   // a blocker lies before the light: 0 < |hit - o|^2 < mt
+// RayTracer::visible over the wide records, one leaf per call (k_st_shadow hands idle lanes new shadow rays; everybody else loops in visible_wide)
+struct VisWalk {
+    WRay wr;
     WWalk k;
-    if (wwalk_begin(S, W, k, ray, wr, 0.0, tmax)) {
-        for (;;) {
-            int32_t lnode = 0, first = 0, cnt = 0;
-            int lslot = 0;
-            if (!wwalk_next_leaf(W, k, ray, wr, 0.0, tmax, lnode, lslot, first, cnt)) break;
-            GI_DIV(W, 2);
-            auto blocks = [&](const LeafTri& g) -> bool {
-                const int32_t ti = g.tri;
-                double u, v;
-                V3 hp;
-                if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return false;
-                if (!(g.matflags & 2u)) {
-                    const Mat& m = S.mats[g.matflags >> 3];
-                    double alpha = m.opacity * 1.0;
-                    if (FEAT & GI_FEAT_TEX) { double cu = 0, cv = 0; ent_uv(S, g, g.matflags, ti, u, v, hp, cu, cv); alpha = mat_alpha(S, m, cu, cv); }
-                    if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return false;
-                }
-                const double ts = len2(hp - ray.o);
-                return (ts < mt) && (ts > 0);
-            };
-#ifdef GI_WAVE_UNIFORM_LEAVES
-            int32_t first_u, cnt_u;
-            if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
-                bool hit = false;
-                for (int32_t j = 0; j < cnt_u; j++) {     // wave-uniform trip count: the record address stays scalar
-                    const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
-                    GI_DIV(W, 4);
-                    if (!hit) hit = blocks(g);
-                    if (__ballot(!hit) == 0ull) break;
-                }
-                if (hit) return false;
-                continue;
-            }
-#endif
-            for (int32_t j = 0; j < cnt; j++) {
-                GI_DIV(W, 6);
-                if (blocks(S.leaf_tris[first + j])) return false;
-            }
+    double tmax;
+};
+template <int FEAT, class WN>
+GI_HD bool visible_wide_begin(const Scene& S, const WN& W, const Ray& ray, double mt, VisWalk& v)   // false: the segment misses the scene's box
+{
+    v.wr = wray_make(ray);
+    v.tmax = sqrt(mt) - GI_SHADOW_BIAS;
+    v.wr.tc = sqrt(mt) * (1.0 + 1e-9);   // a blocker lies before the light: 0 < |hit - o|^2 < mt
+    return wwalk_begin(S, W, v.k, ray, v.wr, 0.0, v.tmax);
+}
+enum { VIS_DONE = 0, VIS_MORE = 1, VIS_BLOCKED = 2 };
+template <int FEAT, class WN>
+GI_HD int visible_wide_step(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, VisWalk& v)
+{
+    int32_t lnode = 0, first = 0, cnt = 0;
+    int lslot = 0;
+    if (!wwalk_next_leaf(W, v.k, ray, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt)) return VIS_DONE;
+    GI_DIV(W, 2);
+    auto blocks = [&](const LeafTri& g) -> bool {
+        const int32_t ti = g.tri;
+        double u, vv;
+        V3 hp;
+        if (!ent_hit<FEAT>(g, g.matflags, ray, u, vv, hp)) return false;
+        if (!(g.matflags & 2u)) {
+            const Mat& m = S.mats[g.matflags >> 3];
+            double alpha = m.opacity * 1.0;
+            if (FEAT & GI_FEAT_TEX) { double cu = 0, cv = 0; ent_uv(S, g, g.matflags, ti, u, vv, hp, cu, cv); alpha = mat_alpha(S, m, cu, cv); }
+            if (!(rng_draw(rng, P_SHADOW_ALPHA | (light_index << 8), (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return false;
         }
+        const double ts = len2(hp - ray.o);
+        return (ts < mt) && (ts > 0);
+    };
+#ifdef GI_WAVE_UNIFORM_LEAVES
+    int32_t first_u, cnt_u;
+    if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
+        bool hit = false;
+        for (int32_t j = 0; j < cnt_u; j++) {     // wave-uniform trip count: the record address stays scalar
+            const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
+            GI_DIV(W, 4);
+            if (!hit) hit = blocks(g);
+            if (__ballot(!hit) == 0ull) break;
+        }
+        return hit ? VIS_BLOCKED : VIS_MORE;
     }
-    if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:308-316
+#endif
+    for (int32_t j = 0; j < cnt; j++) {
+        GI_DIV(W, 6);
+        if (blocks(S.leaf_tris[first + j])) return VIS_BLOCKED;
+    }
+    return VIS_MORE;
+}
+// what visible() asks of the medium once nothing solid blocks the segment: include/raytracer.h:308-316
+template <int FEAT>
+GI_HD bool visible_through_fog(const Scene& S, const Ray& ray, double mt, const Rng& rng, uint32_t light_index)
+{
+    if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {
         double tmin = 0, tmx = mt;
         if (atmosphere_bounds(S, ray, tmin, tmx)) {
             V3 fh, fc;
@@ -870,6 +882,19 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
         }
     }
     return true;
+}
+template <int FEAT, class WN>
+GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index)
+{
+    VisWalk v;
+    if (visible_wide_begin<FEAT>(S, W, ray, mt, v)) {
+        for (;;) {
+            const int r = visible_wide_step<FEAT>(S, W, ray, mt, rng, light_index, v);
+            if (r == VIS_BLOCKED) return false;
+            if (r == VIS_DONE) break;
+        }
+    }
+    return visible_through_fog<FEAT>(S, ray, mt, rng, light_index);
 }
 
 #if defined(__HIPCC__)
@@ -1074,9 +1099,6 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
 template <int FEAT, class Nodes>
 GI_HD bool visible_nodes(const Scene& S, const Nodes& N, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, Counters* c)
 {
-#ifdef GI_EXP_NO_SHADOW   // measurement aid (never defined in the product build): what the shade stage costs without its shadow walk
-    return true;
-#endif
     if constexpr (Nodes::kWide) {
         if constexpr (Nodes::kCoop) return visible_wide_coop<FEAT>(S, N, ray, mt, rng, light_index);
         else return visible_wide<FEAT>(S, N, ray, mt, rng, light_index);
@@ -1444,11 +1466,7 @@ GI_HD void secondary_ray(const Ray& ray, const Mat& m, V3 color, double tex_a, V
             refDir = sample_phong(reflect(ray.d, norm), (1.0 / (m.roughness)) + 1, sx, sy);
             if (dot(refDir, norm) < 0) refDir = reflect(refDir, norm);
         } else
-#ifdef GI_EXP_NO_LOBE
-            refDir = norm + v3(sx, sy, 0.1);
-#else
             refDir = hemi_cos_n(norm, (float)sx, (float)sy, 2);
-#endif
         f = 1.0 * color;
         V3 inf = color;
         contrib = contrib * inf;
@@ -1544,11 +1562,17 @@ GI_HD uint32_t coherence_key(const Scene& S, V3 o, V3 d)
     return (oct << 24) | (m << 6) | db;
 }
 struct ShadeOut { uint32_t key; V3 gpos; };   // by-products of the shade stage for the queues: sort key of the next ray, position of the gather query
+// A shadow query put off: with one light the vertex adds either A = T * (color * i + emissive) -- light visible -- or A0 = T * (color * 0 +
+// emissive) to the path's radiance, so the shade stage can leave the walk to a kernel of its own (k_st_shadow: lanes take a new query as
+// soon as theirs is answered) that adds the one or the other to the per-sample buffer.  A0 is zero unless the surface emits; then it waits
+// in the record's (otherwise idle) L field.  Same bits as the inline form.
+struct ShadowQ { double o[3], dir[3], A[3]; uint32_t idx, stream; int32_t depth; uint32_t live, slot, pad; };   // 96 B; idx = the sample's place in the radiance buffer; live: 0 no query, 1 query, 2 query + A0
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
-template <int FEAT, class Nodes>
 // Lext: where the path's radiance accumulates when it does not live in the record (streaming pipeline: the per-sample radiance buffer,
-// so that a path that ends -- 96 % of the benchmark's reflected rays leave the scene -- has nothing left to read or write); else p.L
-GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr, double* Lext = nullptr)
+// so that a path that ends -- 96 % of the benchmark's reflected rays leave the scene -- has nothing left to read or write); else p.L.
+// DEFER (scenes with one light): the shadow walk is put off (sq), this function then contains no walk and touches no radiance at all.
+template <int FEAT, class Nodes, int DEFER = 0>
+GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr, double* Lext = nullptr, ShadowQ* sq = nullptr)
 {
     double* const Lp = Lext ? Lext : p.L;
     Rng rng = rng_make(seed, p.stream);
@@ -1558,18 +1582,10 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     Ray ray = make_ray_exact(ld3(p.o), ld3(p.d));
     HitRec h;
     h.pos = ld3(p.hpos); h.u = p.hu; h.v = p.hv; h.tri = p.htri; h.mf = p.pad;
-#ifdef GI_EXP_NO_HALTON   // measurement aids (never defined in the product build): the cost of single pieces of the shade stage
-    float sx = 0.3f, sy = 0.6f;
-#else
     float sx = halton_sample(S, 2 + 2 * depth, p.stream);
     float sy = halton_sample(S, 3 + 2 * depth, p.stream);
-#endif
     const Mat& m = S.mats[h.mf >> 3];
-#if defined(GI_EXP_SHADE) && GI_EXP_SHADE >= 2
-    V3 norm = v3(0, 1, 0);
-#else
     V3 norm = shading_normal(S, h);
-#endif
     V3 color = ld3(m.diffuse), emissive = ld3(m.emissive);
     double tex_a = 1;
     if (FEAT & GI_FEAT_TEX) {   // diffuse->get(minUV), emissive->get(minUV), diffuse->getAlpha(minUV): include/raytracer.h:200,269,486
@@ -1596,21 +1612,27 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
             }
         }
     }
-    for (int li = 0; li < S.n_light; li++) {
+    constexpr bool defer = DEFER != 0;
+    const bool emits = emissive.x != 0.0 || emissive.y != 0.0 || emissive.z != 0.0;
+    if (defer) { sq->live = emits ? 2u : 1u; sq->stream = p.stream; sq->depth = depth; }
+    for (int li = 0; li < (defer ? 1 : S.n_light); li++) {
         const LightD& lt = S.lights[li];
         double ry = rng_draw(rng, P_LIGHT_Y | ((uint32_t)li << 8));
         double rx = rng_draw(rng, P_LIGHT_X | ((uint32_t)li << 8));
         V3 lpos = ld3(lt.pos);
         V3 so = h.pos + GI_SHADOW_BIAS * norm;
-#ifdef GI_EXP_NO_LIGHT_SAMPLE
-        V3 lightDir = (lpos + lt.rad * v3(rx, ry, 0.5)) - so;
-#else
         V3 lightDir = (lpos + lt.rad * random_unit_vec(rx, ry)) - so;
-#endif
         double maxt = len2(lightDir);
         double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
-        Ray sray = make_ray(so, lightDir);
-        if (visible_nodes<FEAT>(S, N, sray, maxt, rng, (uint32_t)li, c)) {
+        bool vis = true;
+        if constexpr (defer) {   // the walk happens in k_st_shadow, from these two vectors
+            sq->o[0] = so.x; sq->o[1] = so.y; sq->o[2] = so.z;
+            sq->dir[0] = lightDir.x; sq->dir[1] = lightDir.y; sq->dir[2] = lightDir.z;
+        } else {
+            Ray sray = make_ray(so, lightDir);
+            vis = visible_nodes<FEAT>(S, N, sray, maxt, rng, (uint32_t)li, c);
+        }
+        if (vis) {
             double d = dot(norm, normalize(lpos - h.pos));
             if (d < 0) d = 0;
             // pow(d, 1/roughness): exact shortcuts for the two exponents every constant-texture scene uses (x^1 = x; x^inf for a
@@ -1620,19 +1642,19 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
             i = ld3(lt.col) * l * hfrac;
         }
     }
-#if !defined(GI_EXP_SHADE) || GI_EXP_SHADE < 3
     p.contrib[0] = contrib.x; p.contrib[1] = contrib.y; p.contrib[2] = contrib.z;
-#endif
-    V3 T = depth == 0 ? v3(1, 1, 1) : ld3(p.T), L = depth == 0 ? v3(0, 0, 0) : ld3(Lp);
+    V3 T = depth == 0 ? v3(1, 1, 1) : ld3(p.T), L = (defer || depth == 0) ? v3(0, 0, 0) : ld3(Lp);
     double q = comp_max(contrib);
     if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
         f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
-        L = L + T * (color * i + emissive);
-#if defined(GI_EXP_SHADE) && GI_EXP_SHADE >= 3
-        if (L.x == 1.2345e300) p.L[0] = L.x + refDir.x + contrib.x + f.x;   // keeps the arithmetic alive, stores nothing
-        return ST_CONTINUE | ST_GATHER;
-#endif
-        Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
+        if constexpr (defer) {
+            const V3 A = T * (color * i + emissive);
+            sq->A[0] = A.x; sq->A[1] = A.y; sq->A[2] = A.z;
+            if (emits) { const V3 A0 = T * (color * v3(0, 0, 0) + emissive); p.L[0] = A0.x; p.L[1] = A0.y; p.L[2] = A0.z; }
+        } else {
+            L = L + T * (color * i + emissive);
+            Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
+        }
         int flags = 0;
         if (depth <= 10 && S.n_pnode > 0) {   // caustic = depth <= 10 ? samplePhotons(minHit, refDir, 32) : 0, include/raytracer.h:258
             V3 gc = T * color;
@@ -1650,8 +1672,14 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         if (p.depth <= GI_MAX_DEPTH) flags |= ST_CONTINUE;   // radiance() returns 0 past MAX_DEPTH
         return flags;
     }
-    L = L + T * (color * i);
-    Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
+    if constexpr (defer) {
+        const V3 A = T * (color * i);
+        sq->A[0] = A.x; sq->A[1] = A.y; sq->A[2] = A.z;
+        if (emits) sq->live = 1u;   // the path ends without the surface's own light: the hidden case adds T * (color * 0) = 0
+    } else {
+        L = L + T * (color * i);
+        Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
+    }
     return 0;
 }
 GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)

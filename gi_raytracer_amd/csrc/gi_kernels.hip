@@ -612,10 +612,10 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
 #endif
 }
 
-template <int FEAT, int WIDE>
+template <int FEAT, int WIDE, int DEFER>
 __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, const StreamCtl* ctl, unsigned int* bc, uint32_t* segs, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, double* g_pos,
-                                                       uint32_t* q_free, double* lbuf)
+                                                       uint32_t* q_free, double* lbuf, ShadowQ* shq)
 {
     // the waves of a workgroup take its items 64 at a time from a counter in LDS (in the 128 bytes the wide records leave free) instead of
     // a fixed share each: a wave that drew cheap items takes more of them
@@ -646,39 +646,101 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
         so.key = 0; so.gpos = v3(0, 0, 0);
         if (valid) {
             slot = q_shade[i];
-#if GI_EXP_SHADE >= 5   // measurement aids (never defined in the product build): bisecting the cost of the shade stage
-            fl = ST_CONTINUE | ST_GATHER;
-#else
-            fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr, &so, lbuf + (slot_sample[slot] - sample0) * 3);
-#endif
+            if constexpr (DEFER != 0) {
+                fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, 1>(S, N, pool[slot], seed, nullptr, &so, nullptr, shq + i);
+                shq[i].idx = (uint32_t)(slot_sample[slot] - sample0);
+                shq[i].slot = slot;
+            } else
+                fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr, &so, lbuf + (slot_sample[slot] - sample0) * 3);
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
-#if GI_EXP_SHADE >= 4
-        if (cont && slot == 0xfffffff0u) q_cont[0] = slot;
-        continue;
-#endif
         const uint32_t a = wave_append(c_cont, cont);
-#if GI_EXP_SHADE >= 1
-        if (cont) { q_cont[seg + a] = slot; k_cont[seg + a] = slot >> 8; }
-#else
         if (cont) { q_cont[seg + a] = slot; k_cont[seg + a] = so.key; }   // the key of the next ray, from the registers that just held it
-#endif
         const uint32_t g = wave_append(c_gather, (fl & ST_GATHER) != 0);
         if (fl & ST_GATHER) {
             // the gather query's position goes into the queue as well: the key kernel then reads 24 consecutive bytes per query
             // instead of one scattered sector of the path pool (that read alone kept it at HBM speed)
             q_gather[seg + g] = slot;
-#if GI_EXP_SHADE >= 1
-            g_pos[(size_t)(seg + g) * 3] = 0.1; g_pos[(size_t)(seg + g) * 3 + 1] = 0.1; g_pos[(size_t)(seg + g) * 3 + 2] = 0.1;
-#else
             g_pos[(size_t)(seg + g) * 3] = so.gpos.x; g_pos[(size_t)(seg + g) * 3 + 1] = so.gpos.y; g_pos[(size_t)(seg + g) * 3 + 2] = so.gpos.z;
-#endif
         }
         st_release(slot, q_free + seg, c_free, valid && !cont);
     }
 #ifdef GI_EXP_DIV
     if constexpr (WIDE != 0) div_flush(N, 1);
+#endif
+}
+
+// The shadow queries the shade stage put off (ShadowQ, entry i = item i of the shade queue): RayTracer::visible towards the scene's one
+// light, then L += A where the light is visible.  Lanes work like k_st_trace's: whoever has his answer waits until `refill_min` lanes of
+// the wave are idle, then they write their results and take the next queries of the workgroup's share.  Inside the shade kernel these walks
+// ran with 15-40 % of the lanes (a wave waited for its longest segment, under the register pressure of the whole shade stage).
+template <int FEAT>
+__global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min)
+{
+    unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
+    if (threadIdx.x == 0) *s_next = 0u;
+    const LdsWide N = stage_wide_in_lds(S);   // ends with a barrier
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_in = ctl->n_shade, bs = blockDim.x;
+    const uint32_t total = seg_start(blockIdx.x + 1, n_in, gridDim.x, bs) - seg_start(blockIdx.x, n_in, gridDim.x, bs);
+    bool walking = false, pend = false, blocked = false;
+    uint32_t item = 0;
+    Ray ray = make_ray_exact(v3(0, 0, 0), v3(1, 0, 0));
+    double mt = 0;
+    Rng rng = rng_make(seed, 0);
+    VisWalk v;
+    bool more = true;   // wave-uniform
+    for (;;) {
+        const unsigned long long busy = __ballot(walking);
+        if (busy == 0ull || (more && 64u - (uint32_t)__popcll(busy) >= refill_min)) {
+            if (pend) {
+                const ShadowQ& e = shq[item];
+                const bool vis = !blocked && visible_through_fog<FEAT>(S, ray, mt, rng, 0u);
+                double* o = lbuf + (size_t)e.idx * 3;
+                if (e.depth == 0 || vis || e.live == 2u) {
+                    // L += T * (color * i + emissive): i = the light's share when it is visible (A), else 0 (A0: zero unless the surface emits,
+                    // and then L + 0 = L is not worth a write -- except at depth 0, where L = 0 + ... starts the sum)
+                    const V3 add = vis ? ld3(e.A) : (e.live == 2u ? ld3(pool[e.slot].L) : v3(0, 0, 0));
+                    const V3 L = (e.depth == 0 ? v3(0, 0, 0) : ld3(o)) + add;
+                    o[0] = L.x; o[1] = L.y; o[2] = L.z;
+                }
+                pend = false;
+            }
+            if (more) {
+                const unsigned long long want = ~busy;
+                const uint32_t nw = (uint32_t)__popcll(want);
+                const int leader = __ffsll((long long)want) - 1;
+                unsigned int base = 0;
+                if ((int)lane == leader) base = atomicAdd(s_next, nw);
+                base = (unsigned int)__shfl((int)base, leader);
+                more = base + nw < total;
+                if (!walking) {
+                    const uint32_t u = base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                    const uint32_t i = ((u / bs) * gridDim.x + blockIdx.x) * bs + u % bs;
+                    if (u < total && i < n_in && shq[i].live) {
+                        const ShadowQ& e = shq[i];
+                        item = i;
+                        const V3 dir = ld3(e.dir);
+                        ray = make_ray(ld3(e.o), dir);
+                        mt = len2(dir);
+                        rng = rng_make(seed, e.stream);
+                        rng.depth = (uint32_t)e.depth;
+                        blocked = false;
+                        pend = true;      // answered already when the segment misses the scene's box
+                        if (visible_wide_begin<FEAT>(S, N, ray, mt, v)) { walking = true; pend = false; }
+                    }
+                }
+            }
+            if (__ballot(walking || pend) == 0ull) break;
+        }
+        if (walking) {
+            const int r = visible_wide_step<FEAT>(S, N, ray, mt, rng, 0u, v);
+            if (r != VIS_MORE) { walking = false; pend = true; blocked = r == VIS_BLOCKED; }
+        }
+    }
+#ifdef GI_EXP_DIV
+    div_flush(N, 1);
 #endif
 }
 
@@ -796,9 +858,17 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* const heap = lds + wave * (GI_GATHER_K * 64) + lane;                       // element i of this lane's heap at heap[i * 64]
     double (*const cand)[9] = reinterpret_cast<double (*)[9]>(lds + wave * (GI_GATHER_K * 64));   // cand[k] = staged candidate k of this wave
-    const uint32_t n_round = (n_in + 63u) & ~63u;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_round; i0 += gridDim.x * blockDim.x) {
-        const uint32_t i = i0 + lane;
+    // the waves of a workgroup draw its chunks of the grid-stride loop 64 queries at a time (k_st_shade): leaves differ in candidates
+    __shared__ unsigned int s_next;
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
+    const uint32_t total = seg_start(blockIdx.x + 1, n_in, gridDim.x, blockDim.x) - seg_start(blockIdx.x, n_in, gridDim.x, blockDim.x);
+    for (;;) {
+        unsigned int u = 0;
+        if (lane == 0) u = atomicAdd(&s_next, 64u);
+        u = (unsigned int)__shfl((int)u, 0);
+        if (u >= total) break;
+        const uint32_t i = ((u / blockDim.x) * gridDim.x + blockIdx.x) * blockDim.x + u % blockDim.x + lane;
         const bool valid = i < n_in;
         const uint32_t leaf = valid ? keys[i] : 0xffffffffu;
         const uint32_t leaf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
@@ -1115,7 +1185,7 @@ struct DevBuf {
 
 }  // namespace
 
-struct StreamGrids { int init = 0, trace = 0, shade = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0, compact = 0; };
+struct StreamGrids { int init = 0, trace = 0, shade = 0, shadow = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0, compact = 0; };
 
 struct gi_ctx {
     int device = 0;
@@ -1168,6 +1238,8 @@ struct gi_ctx {
     DevBuf<uint32_t> d_gk[2], d_gv[2];   // gather sort: keys / values, in / out
     DevBuf<uint32_t> d_stage[4];         // staging queues the producers append to, one segment per workgroup (k_st_compact closes the gaps)
     DevBuf<double> d_stage_pos;
+    DevBuf<ShadowQ> d_shq;               // shadow queries the shade stage put off (one light, wide records): entry i belongs to item i of the shade queue
+    bool defer_shadows = true;           // GI_DEFER_SHADOWS=0: the shade kernel walks its shadow segments itself
     DevBuf<unsigned int> d_blkcnt;       // per-workgroup append counters [QC_KINDS][GI_MAX_PRODUCER_BLOCKS], 128 bytes apart
     DevBuf<uint32_t> d_segs;             // segment start of every producer workgroup
     DevBuf<uint32_t> d_ck[2], d_cv;      // continuing-ray sort: keys in / out, unsorted slots
@@ -1240,6 +1312,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
+    if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
     if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
     if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."
@@ -1470,12 +1543,14 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
     StreamGrids& g = c->grids;
     if (!g.trace) {
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
-        g.shade = grid_for(c, (const void*)k_st_shade<7, 1>, kLdsNodes, GI_SHADE_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
+        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7>, kLdsNodes, GI_TRACE_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
         g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
     return g;
 }
 // everything the pass loop needs for P paths in flight (the radiance buffer is the caller's)
+// one light, wide records: the shadow walks of the shade stage run in a kernel of their own (ShadowQ)
+static bool defers_shadows(const gi_ctx* c) { return c->defer_shadows && c->S.wnodes != nullptr && c->S.n_light == 1; }
 static int stream_alloc(gi_ctx* c, uint32_t P)
 {
     if (c->d_pool.n < P) HIP_TRY(c, c->d_pool.alloc(P));
@@ -1487,6 +1562,7 @@ static int stream_alloc(gi_ctx* c, uint32_t P)
     const size_t PS = (size_t)P + 4096;   // segments are laid out as if every chunk of a producer's loop were full: up to one chunk of slack
     for (int k = 0; k < 4; k++) if (c->d_stage[k].n < PS) HIP_TRY(c, c->d_stage[k].alloc(PS));
     if (c->d_stage_pos.n < PS * 3) HIP_TRY(c, c->d_stage_pos.alloc(PS * 3));
+    if (defers_shadows(c) && c->d_shq.n < P) HIP_TRY(c, c->d_shq.alloc(P));
     if (!c->d_blkcnt.p) HIP_TRY(c, c->d_blkcnt.alloc((size_t)QC_KINDS * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE));
     if (!c->d_segs.p) HIP_TRY(c, c->d_segs.alloc(GI_MAX_PRODUCER_BLOCKS));
     if (c->d_cv.n < P) HIP_TRY(c, c->d_cv.alloc(P));
@@ -1568,10 +1644,19 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             job.kind[2] = -1; job.gather_queue = -1;
             stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, c->S, job, bc, c->d_segs.p, (uint32_t)G.trace, ctl); stage_end(c);
         }
+        ShadowQ* const shq = defers_shadows(c) ? c->d_shq.p : nullptr;
         // shade: continuing rays (slot + key) -> staging 0 / 1, gather queries (slot + position) -> staging 2 / pos, finished paths -> staging 3
         HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
-        stage_begin(c, STG_SHADE); hipLaunchKernelGGL(tex ? (wide ? k_st_shade<7, 1> : k_st_shade<7, 0>) : wide ? (fog ? k_st_shade<3, 1> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1> : k_st_shade<0, 1>)) : (fog ? k_st_shade<3, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0> : k_st_shade<0, 0>)), dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, bc, c->d_segs.p,
-                           c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf); stage_end(c);
+        auto shade_kernel = shq ? (tex ? k_st_shade<7, 1, 1> : fog ? k_st_shade<3, 1, 1> : sph ? k_st_shade<GI_FEAT_SPHERES, 1, 1> : k_st_shade<0, 1, 1>)
+                                : tex ? (wide ? k_st_shade<7, 1, 0> : k_st_shade<7, 0, 0>) : wide ? (fog ? k_st_shade<3, 1, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1, 0> : k_st_shade<0, 1, 0>)) : (fog ? k_st_shade<3, 0, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0, 0> : k_st_shade<0, 0, 0>));
+        stage_begin(c, STG_SHADE); hipLaunchKernelGGL(shade_kernel, dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, bc, c->d_segs.p,
+                           c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf, shq);
+        if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
+            hipLaunchKernelGGL(tex ? k_st_shadow<7> : fog ? k_st_shadow<3> : sph ? k_st_shadow<GI_FEAT_SPHERES> : k_st_shadow<0>, dim3(G.shadow), dim3(GI_TRACE_BLOCK), kLdsNodes, st,
+                               c->S, F.seed, pool, shq, ctl, lbuf, c->refill_min);
+            launches++;
+        }
+        stage_end(c);
         {
             CompactJob job;
             memset(&job, 0, sizeof job);
@@ -1627,10 +1712,10 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t held = c->d_pool.n * sizeof(PathRec) + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7;   // ours, re-usable
-            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 40;   // record, sample id, 13 queue / key words, sort scratch, staging queues
+            const size_t held = c->d_pool.n * sizeof(PathRec) + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7 + c->d_shq.n * sizeof(ShadowQ);   // ours, re-usable
+            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 40 + (defers_shadows(c) ? sizeof(ShadowQ) : 0);   // record, sample id, 13 queue / key words, sort scratch, staging queues, shadow queries
             const size_t lbuf = (size_t)n_pix * (size_t)std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)) * 24;
-            const size_t avail = (size_t)((double)(free_b + held) * 0.80);
+            const size_t avail = (size_t)((double)(free_b + held) * 0.90);
             if (avail > lbuf) slots_budget = std::min(slots_budget, (avail - lbuf) / per_slot);
             else slots_budget = std::min<size_t>(slots_budget, 1u << 20);
         }
