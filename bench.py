@@ -119,7 +119,7 @@ def roofline_of(scene_name, w, h, spp, photons, world, mode, local_samples, stag
     """The roofline object for one workload; mix = per-sample counts of the reference algorithm (oracle), or None when unknown."""
     pipeline_ms = sum(stages.values()) if stages and sum(stages.values()) > 0 else kernel_ms_avg   # megakernel mode: one launch
     r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-         "kernel": "streaming wavefront pipeline of one frame: k_st_trace (+ path start), k_st_shade, k_st_gkeys + sorts, k_st_gather, k_st_finish, k_st_accum"
+         "kernel": "streaming wavefront pipeline of one frame: k_st_trace (+ path start), k_st_shade, k_st_shadow, k_st_compact (+ gather keys), sorts, k_st_gather, k_st_finish, k_st_accum"
                    if mode == "wavefront" else mode,
          "kernel_ms": pipeline_ms, "frame_ms_event_to_event": kernel_ms_avg, "stage_ms": stages}
     if mix is not None:

@@ -1651,12 +1651,14 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
                                 : tex ? (wide ? k_st_shade<7, 1, 0> : k_st_shade<7, 0, 0>) : wide ? (fog ? k_st_shade<3, 1, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1, 0> : k_st_shade<0, 1, 0>)) : (fog ? k_st_shade<3, 0, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0, 0> : k_st_shade<0, 0, 0>));
         stage_begin(c, STG_SHADE); hipLaunchKernelGGL(shade_kernel, dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, bc, c->d_segs.p,
                            c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf, shq);
+        stage_end(c);
         if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
+            stage_begin(c, STG_SHADE);
             hipLaunchKernelGGL(tex ? k_st_shadow<7> : fog ? k_st_shadow<3> : sph ? k_st_shadow<GI_FEAT_SPHERES> : k_st_shadow<0>, dim3(G.shadow), dim3(GI_TRACE_BLOCK), kLdsNodes, st,
                                c->S, F.seed, pool, shq, ctl, lbuf, c->refill_min);
+            stage_end(c);
             launches++;
         }
-        stage_end(c);
         {
             CompactJob job;
             memset(&job, 0, sizeof job);
