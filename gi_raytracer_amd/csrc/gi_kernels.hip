@@ -612,8 +612,13 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
 #endif
 }
 
+// the walk-free instance fits its registers at 2 waves per SIMD without a spill and runs faster that way (128.. VGPRs, 4 waves: 260 B of
+// scratch per lane, 144 ms on the benchmark; 3 waves 128 ms; 2 waves 128 ms) -- with no walk in it there is little latency left to hide
+#ifndef GI_DEFER_WAVES
+#define GI_DEFER_WAVES 2
+#endif
 template <int FEAT, int WIDE, int DEFER>
-__global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+__global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, const StreamCtl* ctl, unsigned int* bc, uint32_t* segs, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, double* g_pos,
                                                        uint32_t* q_free, double* lbuf, ShadowQ* shq)
 {
@@ -621,7 +626,12 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, 4) void k_st_shade(Scene S, uint64_
     // a fixed share each: a wave that drew cheap items takes more of them
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
     if (WIDE != 0 && threadIdx.x == 0) *s_next = 0u;
-    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // ends with a barrier
+    typename LdsSrc<WIDE>::type N;
+    if constexpr (DEFER != 0) {   // no walk in this instance: the records stay where they are
+        N.g = S.wnodes; N.cboxes = S.cboxes; N.cuse = S.cuse; N.n_l = 0;
+        __syncthreads();
+    } else
+        N = LdsSrc<WIDE>::stage(S);   // ends with a barrier
     const uint32_t n_in = ctl->n_shade;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t seg = seg_start(blockIdx.x, n_in, gridDim.x, blockDim.x);   // this workgroup's segment of the staging queues (k_st_trace)
