@@ -452,7 +452,12 @@ __device__ __forceinline__ void st_release(uint32_t slot, uint32_t* q_free, unsi
     if (finished) q_free[at] = slot;
 }
 
+#ifndef GI_TRACE_BLOCK
 #define GI_TRACE_BLOCK 1024
+#endif
+#ifndef GI_SHADOW_BLOCK
+#define GI_SHADOW_BLOCK 1024
+#endif
 #define GI_SHADE_BLOCK 512
 // New samples are started inside the trace kernel (path regeneration fused into the first trace of the path): item i < g.n_gen takes the
 // i-th free slot and sample id g.id_base + i, builds its primary ray in registers and traces it at once -- a primary ray that misses
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
 // the wave are idle, then they write their results and take the next queries of the workgroup's share.  Inside the shade kernel these walks
 // ran with 15-40 % of the lanes (a wave waited for its longest segment, under the register pressure of the whole shade stage).
 template <int FEAT>
-__global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min)
+__global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min)
 {
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
     if (threadIdx.x == 0) *s_next = 0u;
@@ -1553,7 +1558,7 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
     StreamGrids& g = c->grids;
     if (!g.trace) {
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
-        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7>, kLdsNodes, GI_TRACE_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
+        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7>, kLdsNodes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
         g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
     return g;
@@ -1664,7 +1669,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         stage_end(c);
         if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
             stage_begin(c, STG_SHADE);
-            hipLaunchKernelGGL(tex ? k_st_shadow<7> : fog ? k_st_shadow<3> : sph ? k_st_shadow<GI_FEAT_SPHERES> : k_st_shadow<0>, dim3(G.shadow), dim3(GI_TRACE_BLOCK), kLdsNodes, st,
+            hipLaunchKernelGGL(tex ? k_st_shadow<7> : fog ? k_st_shadow<3> : sph ? k_st_shadow<GI_FEAT_SPHERES> : k_st_shadow<0>, dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsNodes, st,
                                c->S, F.seed, pool, shq, ctl, lbuf, c->refill_min);
             stage_end(c);
             launches++;
