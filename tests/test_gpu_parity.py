@@ -147,6 +147,27 @@ def test_content_culling_changes_nothing_more_scenes(name):
     pc.check_content_culling(gi.RayTracer(0).setScene(scene), scene)
 
 
+@pytest.mark.parametrize("name", ["caustics", "cornell", "spheres", "fog", "textures", "teapot"])
+def test_schedule_knobs_change_nothing(name, monkeypatch):
+    """Where a shadow segment is walked (inside k_st_shade, or put off to k_st_shadow) and how many idle lanes make a wave of k_st_trace /
+    k_st_shadow take new rays (GI_REFILL_MIN; 64 = lockstep waves) are schedules, not arithmetic: the frame is the same bit for bit.  The
+    textured scene has emitting and non-emitting texels on one material (both forms of the put-off query), fog adds the medium's march
+    to the put-off segment."""
+    scene = pc.load_scene(name)
+    frames = []
+    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}):
+        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rt = gi.RayTracer(0).setScene(scene)     # the knobs are read when the context is created
+        if scene.desc().n_light > 0:
+            rt.tracePhotons(4000)
+        frames.append(rt.run(160, 90, min_samples=12, max_samples=12, seed=11))
+    for f in frames[1:]:
+        assert np.array_equal(frames[0].view(np.uint64), f.view(np.uint64))
+
+
 def test_photon_octree_descent_variants_agree():
     scene = pc.load_scene("caustics")
     pc.check_photon_descent(gi.RayTracer(0).setScene(scene), scene)
