@@ -1221,6 +1221,7 @@ struct gi_ctx {
     DevBuf<uint32_t> d_cuse;
     bool cull_enabled = true;         // gi_set_content_culling
     bool sort_cont = true;            // GI_SORT_CONT=0: continuing rays stay in queue order
+    int sort_lo_bit = 0;              // GI_SORT_LO_BIT: lowest key bit the sort of the continuing rays looks at (27-bit key: octant, 18 Morton bits, 6 direction bits)
     uint32_t refill_min = 32;         // GI_REFILL_MIN: idle lanes of a wave that make k_st_trace hand out new rays (64: lockstep waves)
     bool wide_enabled = true;         // gi_set_wide_nodes
     bool pn_planes_ok = false;        // the uploaded photon octree qualifies for the one-record-per-level descent
@@ -1327,6 +1328,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
+    if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
     if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
     if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
@@ -1707,7 +1709,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
             size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
-            if (c->sort_cont) HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, 0, 27, st));
+            if (c->sort_cont) HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, c->sort_lo_bit, 27, st));
             else HIP_TRY(c, hipMemcpyAsync(qcont_out, c->d_cv.p, (size_t)n_cont * 4, hipMemcpyDeviceToDevice, st));   // GI_SORT_CONT=0: queue order (tuning aid)
             stage_end(c);
             launches++;
