@@ -903,12 +903,22 @@ GI_HD bool visible_wide(const Scene& S, const WN& W, const Ray& ray, double mt, 
 // (include/raytracer.h:447-468: take a hit when it is the first or strictly nearer than the best so far; remember if any taken hit
 // lay inside the leaf's box) is reproduced from an exclusive prefix minimum over the lanes: lane j "takes" its hit exactly when
 // d2_j < min(best before the leaf, d2_i of the accepted hits i < j).  The last taking lane holds the final best.
+// The lanes of a wave form 64 / G groups of G lanes (G = WN::kGroup: 64 or 16); a group carries one ray.  Groups walk different rays through
+// the same loops (a group whose ray needs fewer turns sits them out), every collective stays inside the group: shuffles of width G, ballots
+// masked to the group's lanes.
+template <int G> __device__ __forceinline__ unsigned long long group_ballot(bool pred)
+{
+    const unsigned long long b = __ballot(pred);
+    if constexpr (G == 64) return b;
+    else return (b >> ((threadIdx.x & 63u) & ~(unsigned)(G - 1))) & ((1ull << G) - 1ull);
+}
 template <int FEAT, class WN>
 __device__ __forceinline__ bool trace_wide_coop(const Scene& S, const WN& W, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best)
 {
     if constexpr ((FEAT & GI_FEAT_TEX) != 0) return trace_wide<FEAT>(S, W, ray, rng, alpha_purpose, best);   // the carried uv is sequential: every lane walks alone
     else {
-    const int lane = (int)(threadIdx.x & 63u);
+    constexpr int G = WN::kGroup;
+    const int lane = (int)(threadIdx.x & 63u), gl = lane & (G - 1), gb = lane - gl;
     const WRay wr = wray_make(ray);
     bool intersected = false;
     double best_d2 = 0;
@@ -921,8 +931,8 @@ __device__ __forceinline__ bool trace_wide_coop(const Scene& S, const WN& W, con
         bool term = false;
         double lmin[3], lmax[3];
         W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
-        for (int32_t base = 0; base < cnt; base += 64) {
-            const int32_t j = base + lane;
+        for (int32_t base = 0; base < cnt; base += G) {
+            const int32_t j = base + gl;
             bool ok = false;
             double u = 0, v = 0, d2 = INFINITY;
             V3 hp = v3(0, 0, 0);
@@ -938,19 +948,19 @@ __device__ __forceinline__ bool trace_wide_coop(const Scene& S, const WN& W, con
                 }
                 if (ok) d2 = len2(hp - ray.o);
             }
-            double pm = ok ? d2 : INFINITY;   // inclusive prefix minimum over the lanes
-            for (int off = 1; off < 64; off <<= 1) {
-                const double t = __shfl_up(pm, (unsigned)off);
-                if (lane >= off) pm = fmin(pm, t);
+            double pm = ok ? d2 : INFINITY;   // inclusive prefix minimum over the group's lanes
+            for (int off = 1; off < G; off <<= 1) {
+                const double t = __shfl_up(pm, (unsigned)off, G);
+                if (gl >= off) pm = fmin(pm, t);
             }
-            double ex = __shfl_up(pm, 1u);
-            if (lane == 0) ex = INFINITY;
+            double ex = __shfl_up(pm, 1u, G);
+            if (gl == 0) ex = INFINITY;
             if (intersected) ex = fmin(ex, best_d2);
             const bool take = ok && d2 < ex;
-            const unsigned long long tm = __ballot(take);
+            const unsigned long long tm = group_ballot<G>(take);
             if (tm != 0ull) {
-                if (__ballot(take && box_contains(lmin, lmax, hp)) != 0ull) term = true;
-                const int last = 63 - __clzll((long long)tm);
+                if (group_ballot<G>(take && box_contains(lmin, lmax, hp)) != 0ull) term = true;
+                const int last = gb + 63 - __clzll((long long)tm);
                 best.pos = v3(__shfl(hp.x, last), __shfl(hp.y, last), __shfl(hp.z, last));
                 best.u = __shfl(u, last); best.v = __shfl(v, last);
                 best.tri = __shfl(ti, last); best.mf = (uint32_t)__shfl((int)mf, last);
@@ -968,7 +978,8 @@ __device__ __forceinline__ bool visible_wide_coop(const Scene& S, const WN& W, c
 {
     if constexpr ((FEAT & GI_FEAT_TEX) != 0) return visible_wide<FEAT>(S, W, ray, mt, rng, light_index);
     else {
-    const int lane = (int)(threadIdx.x & 63u);
+    constexpr int G = WN::kGroup;
+    const int gl = (int)(threadIdx.x & (unsigned)(G - 1));
     WRay wr = wray_make(ray);
     const double tmax = sqrt(mt) - GI_SHADOW_BIAS;
     wr.tc = sqrt(mt) * (1.0 + 1e-9);
@@ -978,8 +989,8 @@ __device__ __forceinline__ bool visible_wide_coop(const Scene& S, const WN& W, c
             int32_t lnode = 0, first = 0, cnt = 0;
             int lslot = 0;
             if (!wwalk_next_leaf(W, k, ray, wr, 0.0, tmax, lnode, lslot, first, cnt)) break;
-            for (int32_t base = 0; base < cnt; base += 64) {
-                const int32_t j = base + lane;
+            for (int32_t base = 0; base < cnt; base += G) {
+                const int32_t j = base + gl;
                 bool blocks = false;
                 if (j < cnt) {
                     const LeafTri g = S.leaf_tris[first + j];
@@ -992,18 +1003,11 @@ __device__ __forceinline__ bool visible_wide_coop(const Scene& S, const WN& W, c
                     }
                     if (ok) { const double ts = len2(hp - ray.o); blocks = (ts < mt) && (ts > 0); }
                 }
-                if (__ballot(blocks) != 0ull) return false;
+                if (group_ballot<G>(blocks) != 0ull) return false;
             }
         }
     }
-    if ((FEAT & GI_FEAT_FOG) && S.n_fog > 0) {   // include/raytracer.h:308-316
-        double tmin = 0, tmx = mt;
-        if (atmosphere_bounds(S, ray, tmin, tmx)) {
-            V3 fh, fc;
-            if (raymarch(S, ray, fh, fc, tmin, tmx, rng, P_FOG_SHADOW + 16u * light_index)) return false;
-        }
-    }
-    return true;
+    return visible_through_fog<FEAT>(S, ray, mt, rng, light_index);
     }
 }
 #else

@@ -158,7 +158,7 @@ extern "C" int gi_debug_div(unsigned long long* out, int reset)
     return 0;
 }
 #endif
-struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; };   // the same records, one ray per wave (gi_device.h: trace_wide_coop)
+template <int G> struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; static constexpr int kGroup = G; };   // the same records, one ray per group of G lanes (gi_device.h: trace_wide_coop)
 __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S)
 {
     LdsWide N;
@@ -983,11 +983,13 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     if constexpr (WIDE != 0) {
-        // few enough paths for one wave each: all 64 lanes work on the same path, a leaf's triangles tested side by side
-        if (lanes <= 0 && n_in <= coop_factor * n_waves) {
-            LdsWideCoop NC;
+        // few enough paths for one wave each: all 64 lanes work on the same path, a leaf's triangles tested side by side; up to coop_factor
+        // times four as many: a path per group of 16 lanes, four groups walking through the same loops
+        auto coop = [&](auto NC) {
+            constexpr uint32_t G = (uint32_t)decltype(NC)::kGroup, per_wave = 64u / G;
             NC.g = N.g; NC.n_l = N.n_l; NC.cboxes = N.cboxes; NC.cuse = N.cuse;
-            for (uint32_t i = wave; i < n_in; i += n_waves) {
+            const uint32_t grp = lane / G;
+            for (uint32_t i = wave * per_wave + grp; i < n_in; i += n_waves * per_wave) {
                 const uint32_t slot = q_in[i];
                 PathRec p = pool[slot];
                 double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance so far; kept in registers while this stage works on it
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
                     if (!(fl & ST_CONTINUE)) { alive = false; break; }
                     if (++b >= max_bounces) break;
                 }
-                if (lane == 0) {
+                if ((lane & (G - 1u)) == 0u) {
                     Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
                     if (alive) {
                         pool[slot] = p;
@@ -1008,8 +1010,9 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
                     }
                 }
             }
-            return;
-        }
+        };
+        if (lanes <= 0 && n_in <= 2u * n_waves) { coop(LdsWideCoop<64>()); return; }   // up to two paths per wave in a row: still faster than four side by side
+        if (lanes <= 0 && n_in <= coop_factor * 4u * n_waves) { coop(LdsWideCoop<16>()); return; }
     }
     if (lanes <= 0) lanes = (int)min(64u, max(1u, (n_in + n_waves - 1) / n_waves));   // spread the paths evenly over the resident waves
     if (lane >= (uint32_t)lanes) return;
@@ -1271,7 +1274,7 @@ struct gi_ctx {
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
     size_t pool_slots_max = (size_t)1 << 30;    // upper bound on paths in flight; the actual pool is also bounded by free HBM (render_streaming)
     uint32_t finish_threshold = 1u << 17;
-    uint32_t coop_factor = 8;         // finisher stages with at most coop_factor x (resident waves) paths run one path per wave
+    uint32_t coop_factor = 4;         // finisher stages with at most 4 x coop_factor x (resident waves) paths run one path per group of 16 lanes (at most 2 x: one per wave)
     // finisher stages {paths per wave (0: spread evenly over the resident waves), max vertices}; the last stage runs to MAX_DEPTH.
     // Measured on the default frame (tools/stripe_probe.py): one full-wave stage 60 ms, this plan 51 ms; on 1/8 of the rows 40 -> 30 ms.
     std::vector<std::pair<int, int>> finish_plan = {{0, 1}, {0, 1}, {0, 1}, {0, 1}, {0, 2}, {0, 2}, {0, 4}, {0, 8}, {0, GI_MAX_DEPTH + 1}};

@@ -152,11 +152,11 @@ def test_schedule_knobs_change_nothing(name, monkeypatch):
     """Where a shadow segment is walked (inside k_st_shade, or put off to k_st_shadow) and how many idle lanes make a wave of k_st_trace /
     k_st_shadow take new rays (GI_REFILL_MIN; 64 = lockstep waves) are schedules, not arithmetic: the frame is the same bit for bit.  The
     textured scene has emitting and non-emitting texels on one material (both forms of the put-off query), fog adds the medium's march
-    to the put-off segment."""
+    to the put-off segment.  GI_COOP_FACTOR moves the finisher between one path per lane, per group of 16 lanes and per wave."""
     scene = pc.load_scene(name)
     frames = []
-    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}):
-        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN"):
+    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}):
+        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
