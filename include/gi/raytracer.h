@@ -5,7 +5,7 @@
 // signatures (trace, visible, samplePhotons, radiance, tracePhotons, secondaryRay, rayType, raymarch).
 //
 // run() flattens + uploads when the scene is not valid, emits photons on the GPU when the photon map is not valid, then renders the
-// frame in stripes of `progressive_rows` rows through gi_render_host: after every stripe its pixels go through gamma 2.2 / clamp / the
+// frame in stripes (`progressive_rows` = 16 rows first, doubling while a step is shorter than `progressive_ms`) through gi_render_host: after every stripe its pixels go through gamma 2.2 / clamp / the
 // truncating 8-bit store into the shared Image (the display frame fills top to bottom as the reference's does row by row,
 // include/raytracer.h:93-160), and `_running` is polled (include/raytracer.h:98) -- stop() ends run() within one stripe.
 // trace / visible / samplePhotons / radiance / tracePhotons run on the GPU through the C ABI (one-element batches); there is no CPU
@@ -13,6 +13,7 @@
 // secondaryRay / rayType / raymarch are the kernels' per-lane functions evaluated on the host for a single vertex (detail.h) -- the
 // reference draws drand() inside them; here the draws come from the counter RNG keyed by (seed, rng_stream, rng_depth).
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <memory>
@@ -52,38 +53,56 @@ class RayTracer {
         if (!prepare()) return;
         _linear.assign((size_t)w * h * 3, 0.f);
         if (_st->group) { run_on_group(w, h); return; }
-        const int rows = progressive_rows > 0 ? progressive_rows : h;
-        const int n_stripes = (h + rows - 1) / rows;
+        int rows = progressive_rows > 0 ? std::min(progressive_rows, h) : h;
         std::vector<double> lin;
         std::vector<uint8_t> rgb;
-        for (int k = 0; k < n_stripes; k++) {
+        for (int y0 = 0; y0 < h;) {
             if (!_running) return;                                   // RayTracer::stop(), polled per row in the reference (include/raytracer.h:98)
             gi_render_params rp = params(w, h);
-            rp.stripe_h = rows; rp.stripe_rank = k; rp.stripe_world = n_stripes;   // this call renders stripe k only
-            const int y0 = k * rows, nr = std::min(rows, h - y0);
+            rp.stripe_h = rows; rp.stripe_rank = y0 / rows; rp.stripe_world = (h + rows - 1) / rows;   // this call renders one stripe only (y0 is a multiple of rows)
+            const int nr = std::min(rows, h - y0);
+            rows_in_flight = nr;
             lin.resize((size_t)nr * w * 3);
             _cancel = _running ? 0 : 1;
+            const auto t0 = std::chrono::steady_clock::now();
             if (check(gi_render_host(_st->ctx, &rp, lin.data(), 1, nullptr, &_cancel)) != 0) return;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             show_rows(lin.data(), rgb, y0, nr, w);
+            y0 += nr;
+            rows = next_rows(rows, y0, ms);
         }
     }
 
   private:
+    // Stripes grow while a step is shorter than `progressive_ms`: a render call has a floor of some 20 ms whatever its size (the chain of up to 64
+    // dependent bounces of its deepest path), so a frame in 16-row steps would spend nearly all its time there -- the first stripe appears at once,
+    // the following ones double (16, 16, 32, 64, ...; the next start row stays a multiple of the stripe height, which is what the stripe
+    // parameters of the C ABI address) until a step takes long enough for the viewer's 32 ms repaint to show progress.
+    int next_rows(int rows, int y0, double ms) const
+    {
+        return progressive_ms > 0 && progressive_rows > 0 && ms < progressive_ms && y0 % (2 * rows) == 0 ? 2 * rows : rows;
+    }
     // the same frame over every visible GPU (gi_group_*, include/gi_hip.h): each progressive step renders one stripe per device
     void run_on_group(int w, int h)
     {
-        const int rows = progressive_rows > 0 ? progressive_rows : (h + gi_group_size(_st->group) - 1) / gi_group_size(_st->group);
-        const int total = (h + rows - 1) / rows, n = gi_group_size(_st->group);
+        const int n = gi_group_size(_st->group);
+        int rows = progressive_rows > 0 ? std::min(progressive_rows, h) : (h + n - 1) / n;
         std::vector<double> frame((size_t)w * h * 3, 0.0);
         std::vector<uint8_t> rgb;
-        for (int k = 0; k < total; k += n) {
+        for (int y0 = 0; y0 < h;) {
             if (!_running) return;
             gi_render_params rp = params(w, h);
-            const int ns = std::min(n, total - k), y0 = k * rows, nr = std::min(ns * rows, h - y0);
+            const int total = (h + rows - 1) / rows, k = y0 / rows;
+            const int ns = std::min(n, total - k), nr = std::min(ns * rows, h - y0);
+            rows_in_flight = nr;
             _cancel = _running ? 0 : 1;
+            const auto t0 = std::chrono::steady_clock::now();
             const int rc = gi_group_render_host(_st->group, &rp, rows, k, ns, frame.data(), 1, nullptr, &_cancel);
             if (rc != 0) { if (rc != GI_E_CANCELLED) { _st->err = gi_group_last_error(_st->group); fprintf(stderr, "gi: %s\n", _st->err.c_str()); } return; }
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             show_rows(frame.data() + (size_t)y0 * w * 3, rgb, y0, nr, w);
+            y0 += nr;
+            rows = next_rows(rows, y0, ms);
         }
     }
     // gamma(color, 2.2), glm::clamp, (int)(255 c) of rows [y0, y0 + nr) into the shared image: include/raytracer.h:150-157
@@ -207,7 +226,9 @@ class RayTracer {
     double noise_thresh = 0.0015;
     gi::dvec3 ambient = gi::dvec3(0, 0, 0);
     uint64_t seed = 0x9E3779B97F4A7C15ull;   // counter-RNG seed (the reference seeds drand() with time(0))
-    int progressive_rows = 16;                // rows per displayed stripe of run(); 0 = the whole frame in one call
+    int progressive_rows = 16;                // rows of the first displayed stripe of run(); 0 = the whole frame in one call
+    double progressive_ms = 50;               // stripes double while a step takes less than this many ms; 0 = every stripe progressive_rows high
+    volatile int rows_in_flight = 0;          // rows of the step being rendered (they are painted when it ends)
     std::vector<int32_t> devices;             // HIP device ordinals to render on; empty = every visible GPU (the frame's stripes are dealt round-robin)
     volatile int rows_done = 0;               // rows of the current frame already in the Image
     int photons_on_device = 0;                // photons stored by the last on-device emission of run()

@@ -89,7 +89,7 @@ int main(int argc, char** argv)
             const int done = live.rows_done, f = filled_rows();
             if (f < last) monotone = 0;
             if (f > 0 && f < H) partial_seen = 1;
-            if (f > done + 16 * (int)std::max<size_t>(1, live.devices.size())) monotone = 0;   // nothing beyond the stripes in flight (one per device) is ever painted
+            if (f > done + std::max(16, (int)live.rows_in_flight) * (int)std::max<size_t>(1, live.devices.size())) monotone = 0;   // nothing beyond the step in flight (one stripe per device) is ever painted
             last = f; polls++;
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
@@ -100,6 +100,18 @@ int main(int argc, char** argv)
         const int done = live.rows_done, f = filled_rows();
         if (f > 0 && f < H) partial_seen = 1;                      // the frame the GUI is left with is the part rendered so far
         printf("progressive: monotone %d partial_seen %d stopped at row %d of %d (filled %d) in %.1f ms running %d\n", monotone, partial_seen, done, H, f, ms, (int)live.running());
+        // ---- what the growing stripes are for: a whole frame, progressively, in about the time of one call
+        RayTracer whole = raytracer;
+        whole.devices = copy.devices;
+        whole.min_samples = 8; whole.max_samples = 32;   // the reference's default adaptive setting
+        whole.photons = 2000;
+        for (int fixed = 0; fixed < 2; fixed++) {
+            whole.progressive_ms = fixed ? 0 : 50;
+            whole.start();
+            const auto t1 = std::chrono::steady_clock::now();
+            whole.run(1920, 1080);
+            printf("frame 1920x1080 %s stripes: %.0f ms\n", fixed ? "16-row" : "growing", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+        }
     }
     return 0;
 }
