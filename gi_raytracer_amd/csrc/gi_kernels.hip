@@ -364,7 +364,11 @@ __global__ __launch_bounds__(GI_BLOCK) void k_ad_gen(Scene S, Frame F, PixRec* p
                 // pixel may stop at any sample, but which one is decided by the radiances in sample order alone: starting up to B
                 // samples and folding them until the rule says stop (k_ad_accum) takes the same samples in the same order; the
                 // surplus is discarded.  A handful of rounds instead of one per sample of a borderline pixel.
-                n = min(min(B, F.max_samples - s), max(F.min_samples - samps, 8));   // at least the certain ones, at most 8 on speculation
+                // At least the certain ones, at most 8 on speculation -- but a pixel that comes back (the noisy few per cent) and could be
+                // finished for good in this round gets everything it may still take: a round costs its tail (some 25 ms on a 1080p frame)
+                // whatever its size, the surplus samples of those pixels cost next to nothing.
+                const int rem = F.max_samples - s;
+                n = min(min(B, rem), (s >= F.min_samples && rem <= B) ? rem : max(F.min_samples - samps, 8));
                 s0 = s;
             }
             pix[i].n = n;
