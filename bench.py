@@ -127,7 +127,8 @@ def roofline_of(scene_name, w, h, spp, photons, world, mode, local_samples, stag
         a = b * local_samples / (pipeline_ms * 1e-3) / 1e9
         r.update({"achieved": a, "frac": a / HBM_PEAK_GBS, "algorithmic_frac": a / HBM_PEAK_GBS, "algorithmic_bytes_per_sample": b, "per_sample_mix": mix,
                   "note": "achieved / frac follow SURVEY 8(d): bytes the reference algorithm touches per sample / pipeline time.  The scene and photon "
-                          "tables are LDS / L2 resident, so these bytes do not cross the HBM bus: hbm_measured_frac (PMC) is the bus load; the kernels "
+                          "tables are LDS / L2 resident, so these bytes do not cross the HBM bus and the fraction can exceed 1 (a work rate, not a bus "
+                          "load; content-box culling also skips node visits the reference makes): hbm_measured_frac (PMC) is the bus load; the kernels "
                           "are latency / issue bound (profiles/*_sq_pmc.json)."})
         if stages and sum(stages.values()) > 0:
             stage_bytes = {"trace": 32 * mix["V_trace"] + 36 * mix["T_trace"], "shade": 32 * mix["V_shadow"] + 36 * mix["T_shadow"] + 96 * mix["H"], "gather": 36 * mix["P"]}
