@@ -698,6 +698,7 @@ struct GlobalWide {
     mutable uint32_t ds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     template <class F> GI_HDM auto with(int32_t i, F&& f) const { return f(g + i); }
+    GI_HDM uint32_t cull(int32_t node, uint32_t m, const Ray& r, const WRay& wr) const { return cboxes ? content_cull(cboxes, cuse, node, m, r, wr) : m; }
 };
 // walk state: the node, the children of it still to visit (bit k = k-th in order), and the same masks of its ancestors, one
 // byte per level, in a 128-bit shift register (16 levels; deeper trees keep the per-node walk)
@@ -729,12 +730,38 @@ GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr
             GI_DIV(W, 0);
             wwalk_push(k, ca);
             k.m = W.with(ca, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
-            if (W.cboxes && k.m) k.m = content_cull(W.cboxes, W.cuse, ca, k.m, ray, wr);
+            if (k.m) k.m = W.cull(ca, k.m, ray, wr);
             continue;
         }
         lnode = k.node; lslot = slot; first = ca; cnt = cb;
         return true;
     }
+}
+// One turn of the same walk for callers that interleave the turns of different rays (k_st_shadow): WALK_MOVED = went down one level (the box
+// tests of the new node are done), WALK_LEAF = stands on a non-empty leaf, WALK_END = the tree is exhausted.  Ascents are folded into the turn.
+enum { WALK_MOVED = 0, WALK_LEAF = 1, WALK_END = 2 };
+template <class WN>
+GI_HD int wwalk_turn(const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0, int32_t& lnode, int& lslot, int32_t& first, int32_t& cnt)
+{
+    while (k.m == 0) {
+        if (k.node == 0) return WALK_END;
+        const int32_t par = W.with(k.node, [&](const WNode* w) { return w->parent; });
+        wwalk_pop(k, par);
+    }
+    const int kk = __builtin_ctz(k.m);
+    k.m &= k.m - 1;
+    const int slot = kk ^ wr.a;
+    int32_t ca = 0, cb = 0;
+    W.with(k.node, [&](const WNode* w) { ca = w->ca[slot]; cb = w->cb[slot]; return 0; });
+    if (cb < 0) {
+        GI_DIV(W, 0);
+        wwalk_push(k, ca);
+        k.m = W.with(ca, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+        if (k.m) k.m = W.cull(ca, k.m, ray, wr);
+        return WALK_MOVED;
+    }
+    lnode = k.node; lslot = slot; first = ca; cnt = cb;
+    return WALK_LEAF;
 }
 template <class WN>
 GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0)
@@ -742,7 +769,7 @@ GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, co
     k.node = 0; k.m = 0; k.lo = 0; k.hi = 0;
     if (!box_hit(S.root_bmin, S.root_bmax, ray, tmin0, tmax0)) return false;
     k.m = W.with(0, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
-    if (W.cboxes && k.m) k.m = content_cull(W.cboxes, W.cuse, 0, k.m, ray, wr);
+    if (k.m) k.m = W.cull(0, k.m, ray, wr);
     return true;
 }
 // RayTracer::trace over the wide records, one leaf per call: the streaming trace kernel keeps a wave's lanes on different rays and hands a
@@ -830,12 +857,10 @@ GI_HD bool visible_wide_begin(const Scene& S, const WN& W, const Ray& ray, doubl
     return wwalk_begin(S, W, v.k, ray, v.wr, 0.0, v.tmax);
 }
 enum { VIS_DONE = 0, VIS_MORE = 1, VIS_BLOCKED = 2 };
+// does anything in this leaf block the segment?  (the triangle loop of RayTracer::visible for one leaf of the walk)
 template <int FEAT, class WN>
-GI_HD int visible_wide_step(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, VisWalk& v)
+GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, int32_t lnode, int lslot, int32_t first, int32_t cnt)
 {
-    int32_t lnode = 0, first = 0, cnt = 0;
-    int lslot = 0;
-    if (!wwalk_next_leaf(W, v.k, ray, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt)) return VIS_DONE;
     GI_DIV(W, 2);
     auto blocks = [&](const LeafTri& g) -> bool {
         const int32_t ti = g.tri;
@@ -861,14 +886,22 @@ GI_HD int visible_wide_step(const Scene& S, const WN& W, const Ray& ray, double 
             if (!hit) hit = blocks(g);
             if (__ballot(!hit) == 0ull) break;
         }
-        return hit ? VIS_BLOCKED : VIS_MORE;
+        return hit;
     }
 #endif
     for (int32_t j = 0; j < cnt; j++) {
         GI_DIV(W, 6);
-        if (blocks(S.leaf_tris[first + j])) return VIS_BLOCKED;
+        if (blocks(S.leaf_tris[first + j])) return true;
     }
-    return VIS_MORE;
+    return false;
+}
+template <int FEAT, class WN>
+GI_HD int visible_wide_step(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, VisWalk& v)
+{
+    int32_t lnode = 0, first = 0, cnt = 0;
+    int lslot = 0;
+    if (!wwalk_next_leaf(W, v.k, ray, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt)) return VIS_DONE;
+    return visible_leaf_blocks<FEAT>(S, W, ray, mt, rng, light_index, lnode, lslot, first, cnt) ? VIS_BLOCKED : VIS_MORE;
 }
 // what visible() asks of the medium once nothing solid blocks the segment: include/raytracer.h:308-316
 template <int FEAT>

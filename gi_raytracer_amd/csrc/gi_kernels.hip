@@ -119,6 +119,9 @@ __device__ __forceinline__ LdsNodes stage_nodes_in_lds(const Scene& S)
 
 // the same for the wide records (gi_device.h: WNode): 292 of them = every inner node of the BASELINE scenes
 #define GI_LDS_WNODES 292                     // 64 KB of 224-byte records
+#define GI_LDS_CBOX_OFF 65536                 // ... then, in the kernels that can afford it, their content boxes (192 bytes per record) and flag words
+#define GI_LDS_CUSE_OFF (GI_LDS_CBOX_OFF + GI_LDS_WNODES * 192)
+#define GI_LDS_WIDE_BOXES_BYTES (GI_LDS_CUSE_OFF + GI_LDS_WNODES * 4)
 struct LdsWide {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
@@ -126,6 +129,7 @@ struct LdsWide {
     const float* cboxes;      // content boxes of the children (gi_device.h: content_cull), read through L1 / L2; null = no culling
     const uint32_t* cuse;
     int32_t n_l;
+    int32_t n_lc = 0;         // records whose content boxes are staged in LDS too (kernels with one 1024-thread workgroup per CU: 120 KB of the 160)
 #ifdef GI_EXP_DIV
     mutable uint32_t ds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lane / wave counts of: node steps, leaves, triangle tests (scalar path), triangle tests (per-lane path)
 #endif
@@ -133,6 +137,13 @@ struct LdsWide {
     {
         if (i < n_l) return f(reinterpret_cast<const WNode*>(gi_dyn_lds) + i);
         return f(g + i);
+    }
+    // the content boxes of a record's children: every turn of a walk reads them right after the record -- from L2 that is the longest wait of the turn
+    __device__ __forceinline__ uint32_t cull(int32_t node, uint32_t m, const Ray& r, const WRay& wr) const
+    {
+        if (!cboxes) return m;
+        if (node < n_lc) return content_cull(reinterpret_cast<const float*>(gi_dyn_lds + GI_LDS_CBOX_OFF), reinterpret_cast<const uint32_t*>(gi_dyn_lds + GI_LDS_CUSE_OFF), node, m, r, wr);
+        return content_cull(cboxes, cuse, node, m, r, wr);
     }
 };
 #ifdef GI_EXP_DIV
@@ -159,7 +170,7 @@ extern "C" int gi_debug_div(unsigned long long* out, int reset)
 }
 #endif
 template <int G> struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; static constexpr int kGroup = G; };   // the same records, one ray per group of G lanes (gi_device.h: trace_wide_coop)
-__device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S)
+__device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S, bool with_boxes = false)
 {
     LdsWide N;
     N.g = S.wnodes;
@@ -168,12 +179,22 @@ __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S)
     const uint4* src = reinterpret_cast<const uint4*>(S.wnodes);
     uint4* dst = reinterpret_cast<uint4*>(gi_dyn_lds);
     for (int i = threadIdx.x; i < N.n_l * (int)(sizeof(WNode) / 16); i += blockDim.x) dst[i] = src[i];
+    if (with_boxes && S.cboxes) {
+        N.n_lc = N.n_l;
+        const uint4* bsrc = reinterpret_cast<const uint4*>(S.cboxes);
+        uint4* bdst = reinterpret_cast<uint4*>(gi_dyn_lds + GI_LDS_CBOX_OFF);
+        for (int i = threadIdx.x; i < N.n_lc * 12; i += blockDim.x) bdst[i] = bsrc[i];   // 8 children x 6 floats = 12 x 16 bytes per record
+        uint32_t* udst = reinterpret_cast<uint32_t*>(gi_dyn_lds + GI_LDS_CUSE_OFF);
+        for (int i = threadIdx.x; i < N.n_lc; i += blockDim.x) udst[i] = S.cuse[i];
+    }
     __syncthreads();
     return N;
 }
 template <int WIDE> struct LdsSrc;
-template <> struct LdsSrc<0> { typedef LdsNodes type; static __device__ __forceinline__ LdsNodes stage(const Scene& S) { return stage_nodes_in_lds(S); } };
-template <> struct LdsSrc<1> { typedef LdsWide type; static __device__ __forceinline__ LdsWide stage(const Scene& S) { return stage_wide_in_lds(S); } };
+template <> struct LdsSrc<0> { typedef LdsNodes type; static __device__ __forceinline__ LdsNodes stage(const Scene& S) { return stage_nodes_in_lds(S); }
+                         static __device__ __forceinline__ LdsNodes stage_with_boxes(const Scene& S) { return stage_nodes_in_lds(S); } };
+template <> struct LdsSrc<1> { typedef LdsWide type; static __device__ __forceinline__ LdsWide stage(const Scene& S) { return stage_wide_in_lds(S); }
+                         static __device__ __forceinline__ LdsWide stage_with_boxes(const Scene& S) { return stage_wide_in_lds(S, true); } };
 
 // ================================================================================================= wavefront pipeline
 // The frame is rendered in rounds.  In a round every pixel that still wants samples (adaptive loop of RayTracer::run,
@@ -473,6 +494,9 @@ __device__ __forceinline__ void st_release(uint32_t slot, uint32_t* q_free, unsi
 #ifndef GI_SHADOW_BLOCK
 #define GI_SHADOW_BLOCK 1024
 #endif
+#ifndef GI_SHADOW_LEAF_MIN
+#define GI_SHADOW_LEAF_MIN 16   // lanes of a wave that must stand on a leaf before k_st_shadow tests leaves (or nobody is left walking)
+#endif
 #define GI_SHADE_BLOCK 512
 // New samples are started inside the trace kernel (path regeneration fused into the first trace of the path): item i < g.n_gen takes the
 // i-th free slot and sample id g.id_base + i, builds its primary ray in registers and traces it at once -- a primary ray that misses
@@ -499,7 +523,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
     static_assert((size_t)GI_LDS_WNODES * sizeof(WNode) + sizeof(unsigned int) <= (size_t)GI_LDS_NODES * sizeof(TNode), "no room for the fetch counter");
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
     if (WIDE != 0 && threadIdx.x == 0) *s_next = 0u;
-    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // ends with a barrier
+    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage_with_boxes(S);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = g.n_gen + n_a + n_b;
     const uint32_t cs = WIDE != 0 ? (uint32_t)GI_TRACE_CHUNK : blockDim.x;
@@ -712,7 +736,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
 {
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
     if (threadIdx.x == 0) *s_next = 0u;
-    const LdsWide N = stage_wide_in_lds(S);   // ends with a barrier
+    const LdsWide N = stage_wide_in_lds(S, true);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = ctl->n_shade, bs = (uint32_t)GI_TRACE_CHUNK;
     const uint32_t total = seg_start(blockIdx.x + 1, n_in, gridDim.x, bs) - seg_start(blockIdx.x, n_in, gridDim.x, bs);
@@ -722,6 +746,10 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
     double mt = 0;
     Rng rng = rng_make(seed, 0);
     VisWalk v;
+    bool at_leaf = false;
+    int32_t lnode = 0, first = 0, cnt = 0;
+    int lslot = 0;
+    const uint32_t leaf_min = GI_SHADOW_LEAF_MIN;
     bool more = true;   // wave-uniform
     for (;;) {
         const unsigned long long busy = __ballot(walking);
@@ -760,15 +788,26 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
                         rng.depth = (uint32_t)e.depth;
                         blocked = false;
                         pend = true;      // answered already when the segment misses the scene's box
-                        if (visible_wide_begin<FEAT>(S, N, ray, mt, v)) { walking = true; pend = false; }
+                        if (visible_wide_begin<FEAT>(S, N, ray, mt, v)) { walking = true; pend = false; at_leaf = false; }
                     }
                 }
             }
             if (__ballot(walking || pend) == 0ull) break;
         }
-        if (walking) {
-            const int r = visible_wide_step<FEAT>(S, N, ray, mt, rng, 0u, v);
-            if (r != VIS_MORE) { walking = false; pend = true; blocked = r == VIS_BLOCKED; }
+        // One turn of the walk for every lane that is between leaves; a lane that reaches a leaf waits there until `leaf_min` lanes stand on
+        // one (or nobody is left walking), then those test their leaves' triangles together.  A shadow segment takes some ten turns per leaf
+        // it meets: run as "walk to the next leaf, test it" per lane, the turns of a wave ran at the pace of its slowest lane.
+        if (walking && !at_leaf) {
+            const int r = wwalk_turn(N, v.k, ray, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt);
+            if (r == WALK_LEAF) at_leaf = true;
+            else if (r == WALK_END) { walking = false; pend = true; blocked = false; }
+        }
+        const unsigned long long lf = __ballot(walking && at_leaf);
+        if (lf != 0ull && ((uint32_t)__popcll(lf) >= leaf_min || __ballot(walking && !at_leaf) == 0ull)) {
+            if (walking && at_leaf) {
+                at_leaf = false;
+                if (visible_leaf_blocks<FEAT>(S, N, ray, mt, rng, 0u, lnode, lslot, first, cnt)) { walking = false; pend = true; blocked = true; }
+            }
         }
     }
 #ifdef GI_EXP_DIV
@@ -1576,12 +1615,17 @@ static void stage_end(gi_ctx* c)
 }
 
 static const size_t kLdsNodes = (size_t)GI_LDS_NODES * sizeof(TNode);
+static const size_t kLdsWideBoxes = (size_t)GI_LDS_WIDE_BOXES_BYTES;   // wide records + their content boxes: k_st_trace / k_st_shadow, one 1024-thread workgroup per CU
 static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process may drive several devices (gi_group_*)
 {
     StreamGrids& g = c->grids;
     if (!g.trace) {
-        g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsNodes, GI_TRACE_BLOCK);
-        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7>, kLdsNodes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
+        // more than 64 KB of dynamic LDS has to be asked for, per kernel (and per device: the attribute belongs to the loaded code object)
+        const void* big[] = {(const void*)k_st_trace<0, 1>, (const void*)k_st_trace<GI_FEAT_SPHERES, 1>, (const void*)k_st_trace<7, 1>,
+                             (const void*)k_st_shadow<0>, (const void*)k_st_shadow<GI_FEAT_SPHERES>, (const void*)k_st_shadow<3>, (const void*)k_st_shadow<7>};
+        for (const void* k : big) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsWideBoxes);
+        g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsWideBoxes, GI_TRACE_BLOCK);
+        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7>, kLdsWideBoxes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
         g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
     return g;
@@ -1672,7 +1716,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         const size_t bc_bytes = (size_t)QC_KINDS * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE * sizeof(unsigned int);
         // trace: hits -> staging 0, finished paths -> staging 1; compacted into the shade queue and the head of the free list
         HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
-        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, bc, c->d_segs.p,
+        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), wide ? kLdsWideBoxes : kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, bc, c->d_segs.p,
                            c->d_stage[0].p, c->d_stage[1].p, lbuf, c->refill_min); stage_end(c);
         {
             CompactJob job;
@@ -1692,7 +1736,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         stage_end(c);
         if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
             stage_begin(c, STG_SHADE);
-            hipLaunchKernelGGL(tex ? k_st_shadow<7> : fog ? k_st_shadow<3> : sph ? k_st_shadow<GI_FEAT_SPHERES> : k_st_shadow<0>, dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsNodes, st,
+            hipLaunchKernelGGL(tex ? k_st_shadow<7> : fog ? k_st_shadow<3> : sph ? k_st_shadow<GI_FEAT_SPHERES> : k_st_shadow<0>, dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsWideBoxes, st,
                                c->S, F.seed, pool, shq, ctl, lbuf, c->refill_min);
             stage_end(c);
             launches++;
