@@ -156,6 +156,30 @@ def check_render(rt, scene, w, h, spp, photons, adaptive=False, tol=RMSE_TOL, sp
     return rmse, img, ref["lin"]
 
 
+def two_light_scene(with_glass=True):
+    """A floor, a diffuse and a glass (or second diffuse) block, two lights of different colour (no reference scene has more than one): the reference keeps the
+    share of the LAST visible light of a vertex (`i = ...` inside its light loop, include/raytracer.h), photons are emitted per (index, light)."""
+    s = gi.Scene()
+    white = s.add_material(1, 1, 1, (0.8, 0.8, 0.8)); red = s.add_material(1, 1, 1, (0.8, 0.3, 0.2)); glass = s.add_material(0, 0, 1.5, (1, 1, 1))
+    quad = lambda a, b, c, d: [[a, b, c], [a, c, d]]
+    tris, mats = [], []
+    def box(lo, hi, m):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        f = [((x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0)), ((x0, y0, z1), (x0, y1, z1), (x1, y1, z1), (x1, y0, z1)),
+             ((x0, y0, z0), (x0, y1, z0), (x0, y1, z1), (x0, y0, z1)), ((x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0)),
+             ((x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1)), ((x0, y0, z0), (x0, y0, z1), (x1, y0, z1), (x1, y0, z0))]
+        for q in f:
+            tris.extend(quad(*q)); mats.extend([m, m])
+    tris.extend(quad((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4))); mats.extend([white, white])
+    box((-1.6, 0.001, -0.4), (-0.6, 1.0, 0.6), red)
+    box((0.5, 0.001, -0.7), (1.5, 1.2, 0.3), glass if with_glass else white)
+    s.add_triangles(np.array(tris, float), mat_idx=mats)
+    s.add_light((-2.5, 4, 1.5), (9, 7, 5), 0.1)
+    s.add_light((3, 3.5, 2), (3, 5, 9), 0.15)
+    s.set_camera((0.2, 2.2, 5.5), (0, 0.5, 0))
+    return s.rebuild()
+
+
 def check_gather_float_ties(rt_factory):
     """Photons whose squared distances to the query agree to float precision around rank 32: the float-key heap cannot
     separate them, the exact pass must.  40 photons on a ray from the query point, spacing 1e-9."""

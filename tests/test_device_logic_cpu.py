@@ -127,3 +127,13 @@ def test_height_fog_render_and_emission_match_oracle():
     # the medium changes the picture: the same scene without fog is different
     t = scene.tables()
     assert len(t["fog_grid"]) == 6 * 2 * 6 * 64
+
+
+def test_two_lights_match_oracle():
+    """Two lights (no reference scene has more than one): the last visible light's share wins, photons come from both -- the CPU build of the
+    device code against the oracle, with the glass block (glibc on both sides: no libm chaos)."""
+    scene = pc.two_light_scene(True)
+    rt = el.EmulRayTracer().setScene(scene)
+    pc.check_emission(rt, scene, 1000)
+    rmse, img, ref = pc.check_render(rt, scene, 48, 27, 4, 2000)
+    assert rmse < 1e-12 and img.mean() > 1e-3
