@@ -894,21 +894,21 @@ __global__ __launch_bounds__(256) void k_st_compact(Scene S, CompactJob job, con
 #define GI_GCHUNK 64
 #define GI_GATHER_WAVES 4      // waves per SIMD the gather kernel is compiled for (launch bound)
 // Pass 1 of the cooperative path keeps a lane's 32 smallest keys sorted in 32 registers and folds the candidates in 32 at a time:
-// sort the 32 new keys (bitonic network), take min(best[i], new[31 - i]) -- the 32 smallest of the 64, as a bitonic sequence --
-// and merge.  21 branch-free instructions per candidate; the LDS heap costs ~55, because with 64 lanes some lane always has to
+// sort the 32 new keys (odd-even merge sort network), take min(best[i], new[31 - i]) -- the 32 smallest of the 64, as a bitonic sequence --
+// and merge.  18 branch-free instructions per candidate; the LDS heap costs ~55, because with 64 lanes some lane always has to
 // sift, so the wave pays a full sift for nearly every candidate.  The result (tau = 32nd smallest float key) is the same number.
 __device__ __forceinline__ void kce(float& a, float& b) { const float lo = fminf(a, b), hi = fmaxf(a, b); a = lo; b = hi; }
-__device__ __forceinline__ void ksort32(float (&v)[32])
+__device__ __forceinline__ void ksort32(float (&v)[32])   // Batcher's odd-even merge sort: 191 compare-exchanges (the bitonic sorter takes 240)
 {
 #pragma unroll
-    for (int k = 2; k <= 32; k <<= 1)
+    for (int p = 1; p < 32; p <<= 1)
 #pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
+        for (int k = p; k >= 1; k >>= 1)
 #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const int l = i ^ j;
-                if (l > i) { if ((i & k) == 0) kce(v[i], v[l]); else kce(v[l], v[i]); }
-            }
+            for (int j = k % p; j <= 31 - k; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i <= (k - 1 < 31 - j - k ? k - 1 : 31 - j - k); i++)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) kce(v[i + j], v[i + j + k]);
 }
 __device__ __forceinline__ void kmerge32(float (&v)[32])   // bitonic sequence -> ascending
 {
