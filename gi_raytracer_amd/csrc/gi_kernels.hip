@@ -990,9 +990,17 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
                             nk[k] = k0 + k < m ? key : INFINITY;
                         }
                         ksort32(nk);
+                        // the first 32 keys are the best so far as they are; after the last group only the largest of the 32 smallest is wanted,
+                        // which does not need them in order (wave-uniform conditions: the lanes of the wave scan the same candidates)
+                        const bool first_group = c0 == 0 && k0 == 0, last_group = c0 + (int32_t)GI_GCHUNK >= ncand && k0 + 32 >= m;
+                        if (first_group) {
 #pragma unroll
-                        for (int k = 0; k < 32; k++) best[k] = fminf(best[k], nk[31 - k]);
-                        kmerge32(best);
+                            for (int k = 0; k < 32; k++) best[k] = nk[k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 32; k++) best[k] = fminf(best[k], nk[31 - k]);
+                            if (!last_group) kmerge32(best);
+                        }
                     }
                 } else if (valid) {
                     for (int32_t k = 0; k < m; k++) {
@@ -1003,11 +1011,13 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
             }
             if (pass == 0) {
                 // tau = K-th smallest key, K = min(32, ncand) (what the heap's root holds after pass 1 of gather_in_leaf)
-                float tau = best[31];
+                float tau = 0.0f;
                 if (ncand < 32) {
-                    tau = 0.0f;
 #pragma unroll
                     for (int k = 0; k < 32; k++) tau = best[k] < INFINITY ? fmaxf(tau, best[k]) : tau;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 32; k++) tau = fmaxf(tau, best[k]);   // keys are squared distances: >= 0
                 }
                 a.tau = tau;
             }
