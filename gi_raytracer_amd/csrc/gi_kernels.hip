@@ -1003,9 +1003,32 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
                         }
                     }
                 } else if (valid) {
+                    // g_acc per candidate, with the rare case set aside: a candidate whose key EQUALS tau (the 32nd smallest itself; one per
+                    // query, more only when float keys tie) is some lane's business for nearly every candidate of the wave, so its branch --
+                    // a sum of its own, a count, a running maximum -- would run for nearly every candidate.  The loop only notes where such
+                    // candidates are; they are added afterwards, in candidate order, by the same g_acc.
+                    int n_eq = 0;
+                    int32_t k_eq = 0;
                     for (int32_t k = 0; k < m; k++) {
                         const double* q = cand[k];
+                        const double d2 = len2(v3(q[0], q[1], q[2]) - a.pos);
+                        const float key = (float)d2;
+                        if (key < a.tau) {
+                            const V3 contrib = v3(q[6], q[7], q[8]) * dot(v3(q[3], q[4], q[5]), a.dir);
+                            a.s_lt = a.s_lt + contrib; a.c_lt++;
+                        } else if (key == a.tau) {
+                            if (n_eq == 0) k_eq = k;
+                            n_eq++;
+                        }
+                    }
+                    if (n_eq == 1) {
+                        const double* q = cand[k_eq];
                         g_acc(a, v3(q[0], q[1], q[2]), q + 3);
+                    } else if (n_eq > 1) {     // float keys tie at tau: walk on from the first of them
+                        for (int32_t k = k_eq; n_eq > 0 && k < m; k++) {
+                            const double* q = cand[k];
+                            if ((float)len2(v3(q[0], q[1], q[2]) - a.pos) == a.tau) { g_acc(a, v3(q[0], q[1], q[2]), q + 3); n_eq--; }
+                        }
                     }
                 }
             }
