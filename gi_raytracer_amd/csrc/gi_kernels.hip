@@ -119,9 +119,13 @@ __device__ __forceinline__ LdsNodes stage_nodes_in_lds(const Scene& S)
 
 // the same for the wide records (gi_device.h: WNode): 292 of them = every inner node of the BASELINE scenes
 #define GI_LDS_WNODES 292                     // 64 KB of 224-byte records
-#define GI_LDS_CBOX_OFF 65536                 // ... then, in the kernels that can afford it, their content boxes (192 bytes per record) and flag words
-#define GI_LDS_CUSE_OFF (GI_LDS_CBOX_OFF + GI_LDS_WNODES * 192)
-#define GI_LDS_WIDE_BOXES_BYTES (GI_LDS_CUSE_OFF + GI_LDS_WNODES * 4)
+// the kernels that own a CU with one 1024-thread workgroup (k_st_trace, k_st_shadow) use nearly all of its 160 KB: 384 records, a few counters,
+// the records' content boxes (192 bytes each) and flag words
+#define GI_LDS_WNODES_BIG 384
+#define GI_LDS_BIG_CNT_OFF (GI_LDS_WNODES_BIG * 224)
+#define GI_LDS_CBOX_OFF (GI_LDS_BIG_CNT_OFF + 16)
+#define GI_LDS_CUSE_OFF (GI_LDS_CBOX_OFF + GI_LDS_WNODES_BIG * 192)
+#define GI_LDS_WIDE_BOXES_BYTES (GI_LDS_CUSE_OFF + GI_LDS_WNODES_BIG * 4)
 struct LdsWide {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
@@ -175,7 +179,8 @@ __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S, bool with_b
     LdsWide N;
     N.g = S.wnodes;
     N.cboxes = S.cboxes; N.cuse = S.cuse;
-    N.n_l = S.n_wnode < GI_LDS_WNODES ? S.n_wnode : GI_LDS_WNODES;
+    const int cap = with_boxes ? GI_LDS_WNODES_BIG : GI_LDS_WNODES;
+    N.n_l = S.n_wnode < cap ? S.n_wnode : cap;
     const uint4* src = reinterpret_cast<const uint4*>(S.wnodes);
     uint4* dst = reinterpret_cast<uint4*>(gi_dyn_lds);
     for (int i = threadIdx.x; i < N.n_l * (int)(sizeof(WNode) / 16); i += blockDim.x) dst[i] = src[i];
@@ -520,8 +525,8 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf, uint32_t refill_min)
 {
     // wide instances: next unfetched item of this workgroup, in its own numbering; lives in the 128 bytes the 292 wide records leave of the 64 KB
-    static_assert((size_t)GI_LDS_WNODES * sizeof(WNode) + sizeof(unsigned int) <= (size_t)GI_LDS_NODES * sizeof(TNode), "no room for the fetch counter");
-    unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
+    static_assert(sizeof(WNode) == 224 && GI_LDS_WIDE_BOXES_BYTES <= 160 * 1024, "LDS layout of the wide trace / shadow kernels");
+    unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + GI_LDS_BIG_CNT_OFF);
     if (WIDE != 0 && threadIdx.x == 0) *s_next = 0u;
     const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage_with_boxes(S);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
 template <int FEAT>
 __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min)
 {
-    unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + (size_t)GI_LDS_WNODES * sizeof(WNode));
+    unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + GI_LDS_BIG_CNT_OFF);
     if (threadIdx.x == 0) *s_next = 0u;
     const LdsWide N = stage_wide_in_lds(S, true);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
