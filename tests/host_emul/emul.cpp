@@ -87,6 +87,35 @@ int emul_visible(Emul* e, int n, const double* q, int32_t* vis)
     }
     return 0;
 }
+// RayTracer::visible the way k_st_shadow walks it: one turn at a time (wwalk_turn), a leaf's triangles when the walk stands on one
+// (visible_leaf_blocks), the medium at the end -- must answer as visible() does.  -1: the scene has no wide records.
+int emul_visible_turns(Emul* e, int n, const double* q, int32_t* vis)
+{
+    if (!e->S.wnodes) return -1;
+    GlobalWide W;
+    W.g = e->S.wnodes; W.cboxes = e->S.cboxes; W.cuse = e->S.cuse;
+    for (int i = 0; i < n; i++) {
+        const double* p = q + (size_t)i * 6;
+        V3 o = v3(p[0], p[1], p[2]), t = v3(p[3], p[4], p[5]);
+        V3 ld = t - o;
+        Ray sr = make_ray(o, ld);
+        const double mt = len2(ld);
+        Rng rng = rng_make(0, (uint32_t)i);
+        VisWalk v;
+        bool blocked = false;
+        if (visible_wide_begin<7>(e->S, W, sr, mt, v)) {
+            for (;;) {
+                int32_t lnode = 0, first = 0, cnt = 0;
+                int lslot = 0;
+                const int r = wwalk_turn(W, v.k, sr, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt);
+                if (r == WALK_END) break;
+                if (r == WALK_LEAF && visible_leaf_blocks<7>(e->S, W, sr, mt, rng, 0u, lnode, lslot, first, cnt)) { blocked = true; break; }
+            }
+        }
+        vis[i] = !blocked && visible_through_fog<7>(e->S, sr, mt, rng, 0u);
+    }
+    return 0;
+}
 int emul_gather(Emul* e, int n, const double* q, double* res3, int32_t* n_cand)
 {
     float heap[GI_GATHER_K * 4];

@@ -45,6 +45,21 @@ def test_visible_matches_reference_table(setup):
     pc.check_visible_table(setup[2], setup[3])
 
 
+def test_turn_wise_shadow_walk_answers_like_visible(setup):
+    """k_st_shadow walks a segment one turn at a time (wwalk_turn) and tests a leaf when it stands on one (visible_leaf_blocks): the same
+    answers as RayTracer::visible's loop, on the fixture's shadow segments and on the adversarial rays (axis-parallel, origins on planes)."""
+    name, scene, rt, fx = setup
+    rays = pc.adversarial_rays(scene, n=3000, seed=9)
+    q = np.concatenate([rays[:, :3], rays[:, :3] + rays[:, 3:6] * 4.0], axis=1)
+    if "shadow_q" in fx:
+        q = np.concatenate([q, fx["shadow_q"][:3000]])
+    turns = rt.visible_turns(q)
+    if turns is None:
+        pytest.skip("no wide records for this tree")
+    assert np.array_equal(turns, rt.visible(q))
+    assert 0 < turns.sum() < len(turns)
+
+
 def test_wide_walk_on_a_deeper_tree():
     scene = pc.load_scene("teapot")
     rt = el.EmulRayTracer().setScene(scene)
