@@ -1531,10 +1531,13 @@ struct alignas(16) PathRec {    // 224 B, one per path in flight (HBM-resident i
     uint32_t pad;               // matflags of the hit (material << 3 | flags): the shade stage needs no entity record for them
                                 // -- the first 64 B are all a new path needs and all the trace stage reads
     double T[3], contrib[3];    // throughput prod f_j ; the reference's `contrib` (roulette weight).  At depth 0 they are 1 and L is 0 by
-    double L[3];                // definition: the stages do not read them there, so a new path does not have to write them (path_begin_lean)
+                                // definition: the stages do not read them there, so a new path does not have to write them (path_begin_lean)
+    double gdir[3], gcoef[3];   // pending photon gather: direction (= refDir) and factor T*color -- bytes 0 .. 159 are what the shade stage writes
+                                // (five whole 32-byte sectors of a 32-byte aligned record), 112 .. 183 what the gather stage reads
     double hpos[3], hu, hv;     // hit of the current segment
-    double gdir[3], gcoef[3];   // pending photon gather: direction (= refDir) and factor T*color
+    double L[3];                // radiance so far where the path is advanced in registers (finisher, megakernel); idle in the streaming passes
 };
+static_assert(sizeof(PathRec) == 224, "PathRec layout");
 enum { ST_CONTINUE = 1, ST_GATHER = 2 };
 
 GI_HD void path_begin_lean(PathRec& p, const Ray& ray, uint32_t sample)   // one 64-byte store: what a depth-0 path consists of
