@@ -119,13 +119,16 @@ __device__ __forceinline__ LdsNodes stage_nodes_in_lds(const Scene& S)
 
 // the same for the wide records (gi_device.h: WNode): 292 of them = every inner node of the BASELINE scenes
 #define GI_LDS_WNODES 292                     // 64 KB of 224-byte records
-// the kernels that own a CU with one 1024-thread workgroup (k_st_trace, k_st_shadow) use nearly all of its 160 KB: 384 records, a few counters,
-// the records' content boxes (192 bytes each) and flag words
+// LDS layout "records + content boxes": cap records, 16 bytes of counters, the records' content boxes (192 bytes each), their flag words.
+// The kernels that own a CU with one 1024-thread workgroup (k_st_trace, k_st_shadow) use nearly all of its 160 KB: 384 records; the one-path-per-
+// group forms of the finisher 292 (and 4 KB of heaps behind them).
 #define GI_LDS_WNODES_BIG 384
-#define GI_LDS_BIG_CNT_OFF (GI_LDS_WNODES_BIG * 224)
-#define GI_LDS_CBOX_OFF (GI_LDS_BIG_CNT_OFF + 16)
-#define GI_LDS_CUSE_OFF (GI_LDS_CBOX_OFF + GI_LDS_WNODES_BIG * 192)
-#define GI_LDS_WIDE_BOXES_BYTES (GI_LDS_CUSE_OFF + GI_LDS_WNODES_BIG * 4)
+#define GI_LDS_CNT_OFF(cap) ((cap) * 224)
+#define GI_LDS_CBOX_OFF(cap) (GI_LDS_CNT_OFF(cap) + 16)
+#define GI_LDS_CUSE_OFF(cap) (GI_LDS_CBOX_OFF(cap) + (cap) * 192)
+#define GI_LDS_BOXES_BYTES(cap) (GI_LDS_CUSE_OFF(cap) + (cap) * 4)
+#define GI_LDS_BIG_CNT_OFF GI_LDS_CNT_OFF(GI_LDS_WNODES_BIG)
+#define GI_LDS_WIDE_BOXES_BYTES GI_LDS_BOXES_BYTES(GI_LDS_WNODES_BIG)
 struct LdsWide {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
@@ -133,7 +136,8 @@ struct LdsWide {
     const float* cboxes;      // content boxes of the children (gi_device.h: content_cull), read through L1 / L2; null = no culling
     const uint32_t* cuse;
     int32_t n_l;
-    int32_t n_lc = 0;         // records whose content boxes are staged in LDS too (kernels with one 1024-thread workgroup per CU: 120 KB of the 160)
+    int32_t n_lc = 0;         // records whose content boxes are staged in LDS too
+    uint32_t box_off = 0, use_off = 0;   // where (GI_LDS_CBOX_OFF / GI_LDS_CUSE_OFF of the kernel's record count)
 #ifdef GI_EXP_DIV
     mutable uint32_t ds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // lane / wave counts of: node steps, leaves, triangle tests (scalar path), triangle tests (per-lane path)
 #endif
@@ -146,7 +150,7 @@ struct LdsWide {
     __device__ __forceinline__ uint32_t cull(int32_t node, uint32_t m, const Ray& r, const WRay& wr) const
     {
         if (!cboxes) return m;
-        if (node < n_lc) return content_cull(reinterpret_cast<const float*>(gi_dyn_lds + GI_LDS_CBOX_OFF), reinterpret_cast<const uint32_t*>(gi_dyn_lds + GI_LDS_CUSE_OFF), node, m, r, wr);
+        if (node < n_lc) return content_cull(reinterpret_cast<const float*>(gi_dyn_lds + box_off), reinterpret_cast<const uint32_t*>(gi_dyn_lds + use_off), node, m, r, wr);
         return content_cull(cboxes, cuse, node, m, r, wr);
     }
 };
@@ -174,12 +178,13 @@ extern "C" int gi_debug_div(unsigned long long* out, int reset)
 }
 #endif
 template <int G> struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; static constexpr int kGroup = G; };   // the same records, one ray per group of G lanes (gi_device.h: trace_wide_coop)
-__device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S, bool with_boxes = false)
+__device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S, bool with_boxes = false, int boxes_cap = GI_LDS_WNODES_BIG)
 {
     LdsWide N;
     N.g = S.wnodes;
     N.cboxes = S.cboxes; N.cuse = S.cuse;
-    const int cap = with_boxes ? GI_LDS_WNODES_BIG : GI_LDS_WNODES;
+    const int cap = with_boxes ? boxes_cap : GI_LDS_WNODES;
+    N.box_off = GI_LDS_CBOX_OFF(cap); N.use_off = GI_LDS_CUSE_OFF(cap);
     N.n_l = S.n_wnode < cap ? S.n_wnode : cap;
     const uint4* src = reinterpret_cast<const uint4*>(S.wnodes);
     uint4* dst = reinterpret_cast<uint4*>(gi_dyn_lds);
@@ -187,9 +192,9 @@ __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S, bool with_b
     if (with_boxes && S.cboxes) {
         N.n_lc = N.n_l;
         const uint4* bsrc = reinterpret_cast<const uint4*>(S.cboxes);
-        uint4* bdst = reinterpret_cast<uint4*>(gi_dyn_lds + GI_LDS_CBOX_OFF);
+        uint4* bdst = reinterpret_cast<uint4*>(gi_dyn_lds + N.box_off);
         for (int i = threadIdx.x; i < N.n_lc * 12; i += blockDim.x) bdst[i] = bsrc[i];   // 8 children x 6 floats = 12 x 16 bytes per record
-        uint32_t* udst = reinterpret_cast<uint32_t*>(gi_dyn_lds + GI_LDS_CUSE_OFF);
+        uint32_t* udst = reinterpret_cast<uint32_t*>(gi_dyn_lds + N.use_off);
         for (int i = threadIdx.x; i < N.n_lc; i += blockDim.x) udst[i] = S.cuse[i];
     }
     __syncthreads();
@@ -1067,67 +1072,82 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
 // advances them at most `max_bounces` vertices, and hands the survivors to stage k+1, which spreads them thinner.  The
 // survivor count stays on the device (n_in_dev): no host round trip between stages.
 #define GI_FINISH_BLOCK 512   // 8 waves: with 64 KB of heaps and 64 KB of octree records one block fills a CU, at the 2 waves per SIMD the registers allow
-template <int FEAT, int WIDE>
+// Three forms of a stage, one kernel each: MODE 0 a path per lane (heaps of 32 keys per lane: 64 KB, and the 292 records), MODE 1 a path per wave,
+// MODE 2 a path per group of 16 lanes -- the latter two keep the records' content boxes in LDS as well (a lone path's bounce is a chain of dependent
+// reads, and the boxes were the one left in L2 on every turn) and one heap per GROUP (its lanes carry the same path and would fill 16 or 64 identical
+// heaps).  Which form a stage runs depends on how many paths reach it -- a count that stays on the device -- so all three are launched and two return at once.
+#define GI_FINISH_COOP_RECORDS GI_LDS_WNODES
+#define GI_FINISH_COOP_HEAP_OFF ((GI_LDS_BOXES_BYTES(GI_FINISH_COOP_RECORDS) + 15) & ~15)
+#define GI_FINISH_COOP_LDS_BYTES (GI_FINISH_COOP_HEAP_OFF + (GI_FINISH_BLOCK / 16) * GI_GATHER_K * 4)
+__device__ __forceinline__ int finish_mode(int wide, int lanes, uint32_t n_in, uint32_t n_waves, uint32_t coop_factor)
+{
+    if (!wide || lanes > 0) return 0;
+    if (n_in <= 2u * n_waves) return 1;                    // up to two paths per wave in a row: still faster than four side by side
+    if (n_in <= coop_factor * 4u * n_waves) return 2;
+    return 0;
+}
+template <int FEAT, int WIDE, int MODE>
 __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                         const uint32_t* q_in, const unsigned int* n_in_dev, uint32_t n_in_host, int lanes, int max_bounces,
                                                         uint32_t* q_out, unsigned int* n_out, double* lbuf, uint32_t coop_factor)
 {
-    __shared__ float heap[GI_GATHER_K * GI_FINISH_BLOCK];
-    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // a lone path's bounce is a chain of dependent node reads: LDS, not L2
     const uint32_t n_in = n_in_dev ? *n_in_dev : n_in_host;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    if (finish_mode(WIDE, lanes, n_in, n_waves, coop_factor) != MODE) return;   // uniform over the grid
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    if constexpr (WIDE != 0) {
-        // few enough paths for one wave each: all 64 lanes work on the same path, a leaf's triangles tested side by side; up to coop_factor
-        // times four as many: a path per group of 16 lanes, four groups walking through the same loops
-        auto coop = [&](auto NC) {
-            constexpr uint32_t G = (uint32_t)decltype(NC)::kGroup, per_wave = 64u / G;
-            NC.g = N.g; NC.n_l = N.n_l; NC.cboxes = N.cboxes; NC.cuse = N.cuse;
-            const uint32_t grp = lane / G;
-            for (uint32_t i = wave * per_wave + grp; i < n_in; i += n_waves * per_wave) {
-                const uint32_t slot = q_in[i];
-                PathRec p = pool[slot];
-                double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance so far; kept in registers while this stage works on it
-                p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
-                bool alive = true;
-                for (int b = 0;;) {
-                    if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; break; }
-                    const int fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
-                    if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_FINISH_BLOCK, nullptr);
-                    if (!(fl & ST_CONTINUE)) { alive = false; break; }
-                    if (++b >= max_bounces) break;
-                }
-                if ((lane & (G - 1u)) == 0u) {
-                    Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
-                    if (alive) {
-                        pool[slot] = p;
-                        q_out[atomicAdd(n_out, 1u)] = slot;
-                    }
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if constexpr (WIDE != 0 && MODE != 0) {
+        constexpr uint32_t G = MODE == 1 ? 64u : 16u, per_wave = 64u / G;
+        const LdsWide N = stage_wide_in_lds(S, true, GI_FINISH_COOP_RECORDS);   // ends with a barrier
+        LdsWideCoop<(int)G> NC;
+        NC.g = N.g; NC.n_l = N.n_l; NC.cboxes = N.cboxes; NC.cuse = N.cuse; NC.n_lc = N.n_lc; NC.box_off = N.box_off; NC.use_off = N.use_off;
+        float* const heap = reinterpret_cast<float*>(gi_dyn_lds + GI_FINISH_COOP_HEAP_OFF) + threadIdx.x / G;   // one heap per group, element i at heap[i * groups]
+        const int heap_stride = (int)(GI_FINISH_BLOCK / G);
+        const uint32_t grp = lane / G;
+        for (uint32_t i = wave * per_wave + grp; i < n_in; i += n_waves * per_wave) {
+            const uint32_t slot = q_in[i];
+            PathRec p = pool[slot];
+            double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance so far; kept in registers while this stage works on it
+            p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
+            bool alive = true;
+            for (int b = 0;;) {
+                if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; break; }
+                const int fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
+                if (fl & ST_GATHER) stage_gather(S, p, heap, heap_stride, nullptr);
+                if (!(fl & ST_CONTINUE)) { alive = false; break; }
+                if (++b >= max_bounces) break;
+            }
+            if ((lane & (G - 1u)) == 0u) {
+                Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
+                if (alive) {
+                    pool[slot] = p;
+                    q_out[atomicAdd(n_out, 1u)] = slot;
                 }
             }
-        };
-        if (lanes <= 0 && n_in <= 2u * n_waves) { coop(LdsWideCoop<64>()); return; }   // up to two paths per wave in a row: still faster than four side by side
-        if (lanes <= 0 && n_in <= coop_factor * 4u * n_waves) { coop(LdsWideCoop<16>()); return; }
-    }
-    if (lanes <= 0) lanes = (int)min(64u, max(1u, (n_in + n_waves - 1) / n_waves));   // spread the paths evenly over the resident waves
-    if (lane >= (uint32_t)lanes) return;
-    for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
-        const uint32_t slot = q_in[i];
-        PathRec p = pool[slot];
-        double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;
-        p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
-        bool alive = true;
-        for (int b = 0;;) {
-            if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; break; }
-            const int fl = stage_shade_nodes<FEAT>(S, N, p, seed, nullptr);
-            if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_FINISH_BLOCK, nullptr);
-            if (!(fl & ST_CONTINUE)) { alive = false; break; }
-            if (++b >= max_bounces) break;
         }
-        Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
-        if (alive) {
-            pool[slot] = p;
-            q_out[atomicAdd(n_out, 1u)] = slot;
+    } else {
+        __shared__ float heap[GI_GATHER_K * GI_FINISH_BLOCK];
+        const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // a lone path's bounce is a chain of dependent node reads: LDS, not L2
+        if (lanes <= 0) lanes = (int)min(64u, max(1u, (n_in + n_waves - 1) / n_waves));   // spread the paths evenly over the resident waves
+        if (lane >= (uint32_t)lanes) return;
+        for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
+            const uint32_t slot = q_in[i];
+            PathRec p = pool[slot];
+            double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;
+            p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
+            bool alive = true;
+            for (int b = 0;;) {
+                if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; break; }
+                const int fl = stage_shade_nodes<FEAT>(S, N, p, seed, nullptr);
+                if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_FINISH_BLOCK, nullptr);
+                if (!(fl & ST_CONTINUE)) { alive = false; break; }
+                if (++b >= max_bounces) break;
+            }
+            Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
+            if (alive) {
+                pool[slot] = p;
+                q_out[atomicAdd(n_out, 1u)] = slot;
+            }
         }
     }
 }
@@ -1653,6 +1673,7 @@ static void stage_end(gi_ctx* c)
 }
 
 static const size_t kLdsNodes = (size_t)GI_LDS_NODES * sizeof(TNode);
+static const size_t kLdsFinishCoop = (size_t)GI_FINISH_COOP_LDS_BYTES;   // the one-path-per-group forms of the finisher: 292 records + content boxes + a heap per group
 static const size_t kLdsWideBoxes = (size_t)GI_LDS_WIDE_BOXES_BYTES;   // wide records + their content boxes: k_st_trace / k_st_shadow, one 1024-thread workgroup per CU
 static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process may drive several devices (gi_group_*)
 {
@@ -1662,9 +1683,12 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
         const void* big[] = {(const void*)k_st_trace<0, 1>, (const void*)k_st_trace<GI_FEAT_SPHERES, 1>, (const void*)k_st_trace<7, 1>,
                              (const void*)k_st_shadow<0>, (const void*)k_st_shadow<GI_FEAT_SPHERES>, (const void*)k_st_shadow<3>, (const void*)k_st_shadow<7>};
         for (const void* k : big) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsWideBoxes);
+        const void* coop[] = {(const void*)k_st_finish<0, 1, 1>, (const void*)k_st_finish<0, 1, 2>, (const void*)k_st_finish<GI_FEAT_SPHERES, 1, 1>, (const void*)k_st_finish<GI_FEAT_SPHERES, 1, 2>,
+                              (const void*)k_st_finish<3, 1, 1>, (const void*)k_st_finish<3, 1, 2>, (const void*)k_st_finish<7, 1, 1>, (const void*)k_st_finish<7, 1, 2>};
+        for (const void* k : coop) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFinishCoop);
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsWideBoxes, GI_TRACE_BLOCK);
         g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7>, kLdsWideBoxes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
-        g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
+        g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1, 0>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
     return g;
 }
@@ -1738,8 +1762,14 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
                 const int lanes = c->finish_plan[k].first, vertices = k + 1 == n_stage ? GI_MAX_DEPTH + 1 : c->finish_plan[k].second;
                 const unsigned int* n_in_dev = k == 0 ? nullptr : c->d_fin_cnt.p + (k - 1);
                 stage_begin(c, STG_FINISH);
-                hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1> : k_st_finish<7, 0>) : wide ? (fogf ? k_st_finish<3, 1> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1> : k_st_finish<0, 1>)) : (fogf ? k_st_finish<3, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0> : k_st_finish<0, 0>)), dim3(G.finish), dim3(GI_FINISH_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
-                                   fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, lbuf, c->coop_factor);
+                auto fin = [&](auto mode) {
+                    constexpr int M = decltype(mode)::value;
+                    hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1, M> : k_st_finish<7, 0, 0>) : wide ? (fogf ? k_st_finish<3, 1, M> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1, M> : k_st_finish<0, 1, M>)) : (fogf ? k_st_finish<3, 0, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0, 0> : k_st_finish<0, 0, 0>)), dim3(G.finish), dim3(GI_FINISH_BLOCK),
+                                       M == 0 ? kLdsNodes : kLdsFinishCoop, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
+                                       fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, lbuf, c->coop_factor);
+                };
+                fin(std::integral_constant<int, 0>());
+                if (wide && lanes <= 0) { fin(std::integral_constant<int, 1>()); fin(std::integral_constant<int, 2>()); launches += 2; }
                 stage_end(c);
                 launches++;
                 uint32_t* t = const_cast<uint32_t*>(fq_in); fq_in = fq_out; fq_out = t;   // both are this chunk's continuation queues
