@@ -1610,7 +1610,7 @@ struct ShadowQ { double o[3], dir[3], A[3]; uint32_t idx, stream; int32_t depth;
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
 // Lext: where the path's radiance accumulates when it does not live in the record (streaming pipeline: the per-sample radiance buffer,
 // so that a path that ends -- 96 % of the benchmark's reflected rays leave the scene -- has nothing left to read or write); else p.L.
-// DEFER (scenes with one light): the shadow walk is put off (sq), this function then contains no walk and touches no radiance at all.
+// DEFER (1: scenes with one light, 2: with several): the shadow walks are put off (sq), this function then contains no walk and touches no radiance at all.
 template <int FEAT, class Nodes, int DEFER = 0>
 GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr, double* Lext = nullptr, ShadowQ* sq = nullptr)
 {
@@ -1652,10 +1652,11 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
             }
         }
     }
-    constexpr bool defer = DEFER != 0;
+    constexpr bool defer = DEFER != 0, multi = DEFER == 2;   // DEFER 2: several lights, one query each (sq[li]); k_st_shadow asks them from the last light down
     const bool emits = emissive.x != 0.0 || emissive.y != 0.0 || emissive.z != 0.0;
-    if (defer) { sq->live = emits ? 2u : 1u; sq->stream = p.stream; sq->depth = depth; }
-    for (int li = 0; li < (defer ? 1 : S.n_light); li++) {
+    const int n_def = multi ? S.n_light : 1;
+    if (defer) for (int li = 0; li < n_def; li++) { sq[li].live = (li == 0 && emits) ? 2u : 1u; sq[li].stream = p.stream; sq[li].depth = depth; }
+    for (int li = 0; li < (defer ? n_def : S.n_light); li++) {
         const LightD& lt = S.lights[li];
         double ry = rng_draw(rng, P_LIGHT_Y | ((uint32_t)li << 8));
         double rx = rng_draw(rng, P_LIGHT_X | ((uint32_t)li << 8));
@@ -1666,8 +1667,8 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         double hfrac = 1 / (GI_PI * len2(lpos - h.pos));
         bool vis = true;
         if constexpr (defer) {   // the walk happens in k_st_shadow, from these two vectors
-            sq->o[0] = so.x; sq->o[1] = so.y; sq->o[2] = so.z;
-            sq->dir[0] = lightDir.x; sq->dir[1] = lightDir.y; sq->dir[2] = lightDir.z;
+            sq[li].o[0] = so.x; sq[li].o[1] = so.y; sq[li].o[2] = so.z;
+            sq[li].dir[0] = lightDir.x; sq[li].dir[1] = lightDir.y; sq[li].dir[2] = lightDir.z;
         } else {
             Ray sray = make_ray(so, lightDir);
             vis = visible_nodes<FEAT>(S, N, sray, maxt, rng, (uint32_t)li, c);
@@ -1681,6 +1682,7 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
             double l = ex == 1.0 ? d : (ex == INFINITY ? (d < 1.0 ? 0.0 : (d == 1.0 ? 1.0 : INFINITY)) : pow(d, ex));
             i = ld3(lt.col) * l * hfrac;
         }
+        if constexpr (multi) { sq[li].A[0] = i.x; sq[li].A[1] = i.y; sq[li].A[2] = i.z; }   // this light's share, until T is known below
     }
     p.contrib[0] = contrib.x; p.contrib[1] = contrib.y; p.contrib[2] = contrib.z;
     V3 T = depth == 0 ? v3(1, 1, 1) : ld3(p.T), L = (defer || depth == 0) ? v3(0, 0, 0) : ld3(Lp);
@@ -1688,8 +1690,11 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
     if (depth <= GI_MIN_DEPTH || rng_draw(rng, P_RR) < q) {
         f = f * (depth <= GI_MIN_DEPTH ? 1.0 : (1.0 / q));
         if constexpr (defer) {
-            const V3 A = T * (color * i + emissive);
-            sq->A[0] = A.x; sq->A[1] = A.y; sq->A[2] = A.z;
+            for (int li = 0; li < n_def; li++) {
+                const V3 il = multi ? ld3(sq[li].A) : i;
+                const V3 A = T * (color * il + emissive);
+                sq[li].A[0] = A.x; sq[li].A[1] = A.y; sq[li].A[2] = A.z;
+            }
             if (emits) { const V3 A0 = T * (color * v3(0, 0, 0) + emissive); p.L[0] = A0.x; p.L[1] = A0.y; p.L[2] = A0.z; }
         } else {
             L = L + T * (color * i + emissive);
@@ -1713,9 +1718,12 @@ GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t
         return flags;
     }
     if constexpr (defer) {
-        const V3 A = T * (color * i);
-        sq->A[0] = A.x; sq->A[1] = A.y; sq->A[2] = A.z;
-        if (emits) sq->live = 1u;   // the path ends without the surface's own light: the hidden case adds T * (color * 0) = 0
+        for (int li = 0; li < n_def; li++) {
+            const V3 il = multi ? ld3(sq[li].A) : i;
+            const V3 A = T * (color * il);
+            sq[li].A[0] = A.x; sq[li].A[1] = A.y; sq[li].A[2] = A.z;
+        }
+        if (emits) sq[0].live = 1u;   // the path ends without the surface's own light: the hidden case adds T * (color * 0) = 0
     } else {
         L = L + T * (color * i);
         Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;

@@ -713,9 +713,10 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
         if (valid) {
             slot = q_shade[i];
             if constexpr (DEFER != 0) {
-                fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, 1>(S, N, pool[slot], seed, nullptr, &so, nullptr, shq + i);
-                shq[i].idx = (uint32_t)(slot_sample[slot] - sample0);
-                shq[i].slot = slot;
+                const int nl = DEFER == 2 ? S.n_light : 1;          // one query per light, the queries of item i side by side
+                ShadowQ* const e = shq + (size_t)i * (size_t)nl;
+                fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, pool[slot], seed, nullptr, &so, nullptr, e);
+                for (int li = 0; li < nl; li++) { e[li].idx = (uint32_t)(slot_sample[slot] - sample0); e[li].slot = slot; }
             } else
                 fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr, &so, lbuf + (slot_sample[slot] - sample0) * 3);
         }
@@ -741,9 +742,13 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
 // light, then L += A where the light is visible.  Lanes work like k_st_trace's: whoever has his answer waits until `refill_min` lanes of
 // the wave are idle, then they write their results and take the next queries of the workgroup's share.  Inside the shade kernel these walks
 // ran with 15-40 % of the lanes (a wave waited for its longest segment, under the register pressure of the whole shade stage).
-template <int FEAT>
+// MULTI: several lights -- the reference keeps the share of the LAST visible light of a vertex, so a lane asks the item's queries from the last light
+// down and stops at the first visible one (the medium's answer is then needed at the end of each walk, not only when the lane retires).
+template <int FEAT, int MULTI>
 __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min)
 {
+    const uint32_t nl = MULTI ? (uint32_t)S.n_light : 1u;
+    uint32_t li = 0;   // the light this lane's walk is about
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + GI_LDS_BIG_CNT_OFF);
     if (threadIdx.x == 0) *s_next = 0u;
     const LdsWide N = stage_wide_in_lds(S, true);   // ends with a barrier
@@ -765,13 +770,14 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
         const unsigned long long busy = __ballot(walking);
         if (busy == 0ull || (more && 64u - (uint32_t)__popcll(busy) >= refill_min)) {
             if (pend) {
-                const ShadowQ& e = shq[item];
-                const bool vis = !blocked && visible_through_fog<FEAT>(S, ray, mt, rng, 0u);
+                const ShadowQ& e0 = shq[(size_t)item * nl];          // the item's first query carries what belongs to the vertex
+                const ShadowQ& e = shq[(size_t)item * nl + li];      // the query of the light that won (or of light 0 when none did)
+                const bool vis = !blocked && (MULTI ? true : visible_through_fog<FEAT>(S, ray, mt, rng, 0u));
                 double* o = lbuf + (size_t)e.idx * 3;
-                if (e.depth == 0 || vis || e.live == 2u) {
+                if (e.depth == 0 || vis || e0.live == 2u) {
                     // L += T * (color * i + emissive): i = the light's share when it is visible (A), else 0 (A0: zero unless the surface emits,
                     // and then L + 0 = L is not worth a write -- except at depth 0, where L = 0 + ... starts the sum)
-                    const V3 add = vis ? ld3(e.A) : (e.live == 2u ? ld3(pool[e.slot].L) : v3(0, 0, 0));
+                    const V3 add = vis ? ld3(e.A) : (e0.live == 2u ? ld3(pool[e.slot].L) : v3(0, 0, 0));
                     const V3 L = (e.depth == 0 ? v3(0, 0, 0) : ld3(o)) + add;
                     o[0] = L.x; o[1] = L.y; o[2] = L.z;
                 }
@@ -788,8 +794,9 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
                 if (!walking) {
                     const uint32_t u = base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
                     const uint32_t i = ((u / bs) * gridDim.x + blockIdx.x) * bs + u % bs;
-                    if (u < total && i < n_in && shq[i].live) {
-                        const ShadowQ& e = shq[i];
+                    if (u < total && i < n_in && shq[(size_t)i * nl].live) {
+                        li = nl - 1u;
+                        const ShadowQ& e = shq[(size_t)i * nl + li];
                         item = i;
                         const V3 dir = ld3(e.dir);
                         ray = make_ray(ld3(e.o), dir);
@@ -799,6 +806,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
                         blocked = false;
                         pend = true;      // answered already when the segment misses the scene's box
                         if (visible_wide_begin<FEAT>(S, N, ray, mt, v)) { walking = true; pend = false; at_leaf = false; }
+                        else if constexpr (MULTI != 0) blocked = !visible_through_fog<FEAT>(S, ray, mt, rng, li);
                     }
                 }
             }
@@ -810,13 +818,29 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
         if (walking && !at_leaf) {
             const int r = wwalk_turn(N, v.k, ray, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt);
             if (r == WALK_LEAF) at_leaf = true;
-            else if (r == WALK_END) { walking = false; pend = true; blocked = false; }
+            else if (r == WALK_END) {
+                walking = false; pend = true; blocked = false;
+                if constexpr (MULTI != 0) blocked = !visible_through_fog<FEAT>(S, ray, mt, rng, li);
+            }
         }
         const unsigned long long lf = __ballot(walking && at_leaf);
         if (lf != 0ull && ((uint32_t)__popcll(lf) >= leaf_min || __ballot(walking && !at_leaf) == 0ull)) {
             if (walking && at_leaf) {
                 at_leaf = false;
-                if (visible_leaf_blocks<FEAT>(S, N, ray, mt, rng, 0u, lnode, lslot, first, cnt)) { walking = false; pend = true; blocked = true; }
+                if (visible_leaf_blocks<FEAT>(S, N, ray, mt, rng, li, lnode, lslot, first, cnt)) { walking = false; pend = true; blocked = true; }
+            }
+        }
+        if constexpr (MULTI != 0) {   // this light is hidden: on to the one before it, in the same lane
+            while (pend && blocked && li > 0u) {
+                li--;
+                const ShadowQ& e = shq[(size_t)item * nl + li];
+                const V3 dir = ld3(e.dir);
+                ray = make_ray(ld3(e.o), dir);
+                mt = len2(dir);
+                blocked = false;
+                at_leaf = false;
+                if (visible_wide_begin<FEAT>(S, N, ray, mt, v)) { walking = true; pend = false; }
+                else blocked = !visible_through_fog<FEAT>(S, ray, mt, rng, li);   // the segment misses the scene's box: only the medium can hide the light
             }
         }
     }
@@ -1681,20 +1705,21 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
     if (!g.trace) {
         // more than 64 KB of dynamic LDS has to be asked for, per kernel (and per device: the attribute belongs to the loaded code object)
         const void* big[] = {(const void*)k_st_trace<0, 1>, (const void*)k_st_trace<GI_FEAT_SPHERES, 1>, (const void*)k_st_trace<7, 1>,
-                             (const void*)k_st_shadow<0>, (const void*)k_st_shadow<GI_FEAT_SPHERES>, (const void*)k_st_shadow<3>, (const void*)k_st_shadow<7>};
+                             (const void*)k_st_shadow<0, 0>, (const void*)k_st_shadow<GI_FEAT_SPHERES, 0>, (const void*)k_st_shadow<3, 0>, (const void*)k_st_shadow<7, 0>,
+                             (const void*)k_st_shadow<0, 1>, (const void*)k_st_shadow<GI_FEAT_SPHERES, 1>, (const void*)k_st_shadow<3, 1>, (const void*)k_st_shadow<7, 1>};
         for (const void* k : big) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsWideBoxes);
         const void* coop[] = {(const void*)k_st_finish<0, 1, 1>, (const void*)k_st_finish<0, 1, 2>, (const void*)k_st_finish<GI_FEAT_SPHERES, 1, 1>, (const void*)k_st_finish<GI_FEAT_SPHERES, 1, 2>,
                               (const void*)k_st_finish<3, 1, 1>, (const void*)k_st_finish<3, 1, 2>, (const void*)k_st_finish<7, 1, 1>, (const void*)k_st_finish<7, 1, 2>};
         for (const void* k : coop) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFinishCoop);
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsWideBoxes, GI_TRACE_BLOCK);
-        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7>, kLdsWideBoxes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
+        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7, 1>, kLdsWideBoxes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
         g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1, 0>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
     return g;
 }
 // everything the pass loop needs for P paths in flight (the radiance buffer is the caller's)
-// one light, wide records: the shadow walks of the shade stage run in a kernel of their own (ShadowQ)
-static bool defers_shadows(const gi_ctx* c) { return c->defer_shadows && c->S.wnodes != nullptr && c->S.n_light == 1; }
+// a few lights, wide records: the shadow walks of the shade stage run in a kernel of their own (ShadowQ)
+static bool defers_shadows(const gi_ctx* c) { return c->defer_shadows && c->S.wnodes != nullptr && c->S.n_light >= 1 && c->S.n_light <= 4; }   // one query per light and shaded hit
 static int stream_alloc(gi_ctx* c, uint32_t P)
 {
     if (c->d_pool.n < P) HIP_TRY(c, c->d_pool.alloc(P));
@@ -1706,7 +1731,7 @@ static int stream_alloc(gi_ctx* c, uint32_t P)
     const size_t PS = (size_t)P + 4096;   // segments are laid out as if every chunk of a producer's loop were full: up to one chunk of slack
     for (int k = 0; k < 4; k++) if (c->d_stage[k].n < PS) HIP_TRY(c, c->d_stage[k].alloc(PS));
     if (c->d_stage_pos.n < PS * 3) HIP_TRY(c, c->d_stage_pos.alloc(PS * 3));
-    if (defers_shadows(c) && c->d_shq.n < P) HIP_TRY(c, c->d_shq.alloc(P));
+    if (defers_shadows(c) && c->d_shq.n < (size_t)P * (size_t)c->S.n_light) HIP_TRY(c, c->d_shq.alloc((size_t)P * (size_t)c->S.n_light));
     if (!c->d_blkcnt.p) HIP_TRY(c, c->d_blkcnt.alloc((size_t)QC_KINDS * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE));
     if (!c->d_segs.p) HIP_TRY(c, c->d_segs.alloc(GI_MAX_PRODUCER_BLOCKS));
     if (c->d_cv.n < P) HIP_TRY(c, c->d_cv.alloc(P));
@@ -1797,14 +1822,17 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         ShadowQ* const shq = defers_shadows(c) ? c->d_shq.p : nullptr;
         // shade: continuing rays (slot + key) -> staging 0 / 1, gather queries (slot + position) -> staging 2 / pos, finished paths -> staging 3
         HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
-        auto shade_kernel = shq ? (tex ? k_st_shade<7, 1, 1> : fog ? k_st_shade<3, 1, 1> : sph ? k_st_shade<GI_FEAT_SPHERES, 1, 1> : k_st_shade<0, 1, 1>)
+        const bool many = c->S.n_light > 1;
+        auto shade_kernel = shq ? (many ? (tex ? k_st_shade<7, 1, 2> : fog ? k_st_shade<3, 1, 2> : sph ? k_st_shade<GI_FEAT_SPHERES, 1, 2> : k_st_shade<0, 1, 2>)
+                                        : (tex ? k_st_shade<7, 1, 1> : fog ? k_st_shade<3, 1, 1> : sph ? k_st_shade<GI_FEAT_SPHERES, 1, 1> : k_st_shade<0, 1, 1>))
                                 : tex ? (wide ? k_st_shade<7, 1, 0> : k_st_shade<7, 0, 0>) : wide ? (fog ? k_st_shade<3, 1, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1, 0> : k_st_shade<0, 1, 0>)) : (fog ? k_st_shade<3, 0, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0, 0> : k_st_shade<0, 0, 0>));
         stage_begin(c, STG_SHADE); hipLaunchKernelGGL(shade_kernel, dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, bc, c->d_segs.p,
                            c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf, shq);
         stage_end(c);
         if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
             stage_begin(c, STG_SHADE);
-            hipLaunchKernelGGL(tex ? k_st_shadow<7> : fog ? k_st_shadow<3> : sph ? k_st_shadow<GI_FEAT_SPHERES> : k_st_shadow<0>, dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsWideBoxes, st,
+            hipLaunchKernelGGL(many ? (tex ? k_st_shadow<7, 1> : fog ? k_st_shadow<3, 1> : sph ? k_st_shadow<GI_FEAT_SPHERES, 1> : k_st_shadow<0, 1>)
+                                    : (tex ? k_st_shadow<7, 0> : fog ? k_st_shadow<3, 0> : sph ? k_st_shadow<GI_FEAT_SPHERES, 0> : k_st_shadow<0, 0>), dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsWideBoxes, st,
                                c->S, F.seed, pool, shq, ctl, lbuf, c->refill_min);
             stage_end(c);
             launches++;
@@ -1865,7 +1893,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t held = c->d_pool.n * sizeof(PathRec) + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7 + c->d_shq.n * sizeof(ShadowQ);   // ours, re-usable
-            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 40 + (defers_shadows(c) ? sizeof(ShadowQ) : 0);   // record, sample id, 13 queue / key words, sort scratch, staging queues, shadow queries
+            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 40 + (defers_shadows(c) ? sizeof(ShadowQ) * (size_t)c->S.n_light : 0);   // record, sample id, 13 queue / key words, sort scratch, staging queues, shadow queries
             const size_t lbuf = (size_t)n_pix * (size_t)std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)) * 24;
             const size_t avail = (size_t)((double)(free_b + held) * 0.90);
             if (avail > lbuf) slots_budget = std::min(slots_budget, (avail - lbuf) / per_slot);

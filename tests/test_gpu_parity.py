@@ -147,13 +147,13 @@ def test_content_culling_changes_nothing_more_scenes(name):
     pc.check_content_culling(gi.RayTracer(0).setScene(scene), scene)
 
 
-@pytest.mark.parametrize("name", ["caustics", "cornell", "spheres", "fog", "textures", "teapot"])
+@pytest.mark.parametrize("name", ["caustics", "cornell", "spheres", "fog", "textures", "teapot", "two_lights", "two_lights_glass"])
 def test_schedule_knobs_change_nothing(name, monkeypatch):
     """Where a shadow segment is walked (inside k_st_shade, or put off to k_st_shadow) and how many idle lanes make a wave of k_st_trace /
     k_st_shadow take new rays (GI_REFILL_MIN; 64 = lockstep waves) are schedules, not arithmetic: the frame is the same bit for bit.  The
     textured scene has emitting and non-emitting texels on one material (both forms of the put-off query), fog adds the medium's march
     to the put-off segment.  GI_COOP_FACTOR moves the finisher between one path per lane, per group of 16 lanes and per wave."""
-    scene = pc.load_scene(name)
+    scene = pc.two_light_scene(name.endswith("glass")) if name.startswith("two_lights") else pc.load_scene(name)   # two lights: one put-off query per light
     frames = []
     for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}):
         for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR"):
