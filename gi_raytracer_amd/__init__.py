@@ -11,7 +11,11 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GI_LIB_PATH") or os.path.join(_HERE, "libgi_raytracer_hip.so")   # GI_LIB_PATH: an experimental build of the same library (tuning aid)
+# The product library, in-tree.  An experimental build of the same library (tools/build_exp.sh -> exp/*.so) is loaded instead only when
+# BOTH GI_EXPERIMENTAL=1 and GI_LIB_PATH are set (the tuning scripts under tools/ set them); bench.py prints the path it resolved.
+LIB_PATH = os.path.join(_HERE, "libgi_raytracer_hip.so")
+if os.environ.get("GI_EXPERIMENTAL") == "1" and os.environ.get("GI_LIB_PATH"):
+    LIB_PATH = os.environ["GI_LIB_PATH"]
 DEFAULT_SEED = 0x9E3779B97F4A7C15
 
 GI_OK, GI_E_NO_DEVICE, GI_E_INVALID, GI_E_HIP, GI_E_STATE, GI_E_CANCELLED = 0, -1, -2, -3, -4, -5
@@ -437,6 +441,10 @@ class RayTracer:
         d = self.scene.photon_desc()
         self._check(self.L.gi_upload_photons(self.h, C.byref(d)), "upload_photons")
 
+    def clear_photons(self):
+        """Drop the photon map (an empty PhotonMap: samplePhotons returns 0, include/raytracer.h:536-540)."""
+        self._check(self.L.gi_clear_photons(self.h), "clear_photons")
+
     def tracePhotons(self, count=None, max_depth=5, seed=None):
         """RayTracer::tracePhotons(5, photons, ...) on the device, then PhotonMap::rebuild on the host and upload
         (include/raytracer.h:61-72,582-715).  Returns (photons [n][9], emission tries)."""
@@ -568,7 +576,7 @@ class RayTracer:
         self._check(self.L.gi_radiance(self.h, len(rays), _p(rays), _p(stream, _up), C.c_uint64(self.seed if seed is None else seed), _p(out)), "radiance")
         return out
 
-    KAT = {"fastPow": 0, "fastPrecisePow": 1, "hemisphereSample_cos": 2, "sample_phong": 3, "sphereCapSample_cos": 4, "randomUnitVec": 5, "refr": 6, "reflect": 7,
+    KAT = {"fastPow": 0, "fastPrecisePow": 1, "hemisphereSample_cos": 2, "sample_phong": 3, "sphereCapSample_cos": 4, "randomUnitVec": 5, "refr": 6, "reflect": 7, "rng": 8,
            "sin": 16, "cos": 17, "acos": 18, "asin": 19, "atan2": 20, "pow": 21, "sqrt": 22}
 
     def kat(self, what, args):

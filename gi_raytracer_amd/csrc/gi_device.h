@@ -1236,7 +1236,7 @@ GI_HD int leaf_order(const Scene& S, const Ray& ray, int cap, int32_t* out)
 }
 // Known-answer access to the scalar building blocks (include/util.h:100-188, include/util.cpp:27-107) and to the libm calls the path
 // makes, as the device evaluates them.  in: up to 9 doubles, out: 3 doubles.
-enum { KAT_FAST_POW = 0, KAT_FAST_PRECISE_POW = 1, KAT_HEMI_COS_N = 2, KAT_SAMPLE_PHONG = 3, KAT_SPHERE_CAP = 4, KAT_UNIT_VEC = 5, KAT_REFR = 6, KAT_REFLECT = 7,
+enum { KAT_FAST_POW = 0, KAT_FAST_PRECISE_POW = 1, KAT_HEMI_COS_N = 2, KAT_SAMPLE_PHONG = 3, KAT_SPHERE_CAP = 4, KAT_UNIT_VEC = 5, KAT_REFR = 6, KAT_REFLECT = 7, KAT_RNG = 8,
        KAT_SIN = 16, KAT_COS = 17, KAT_ACOS = 18, KAT_ASIN = 19, KAT_ATAN2 = 20, KAT_POW = 21, KAT_SQRT = 22 };
 GI_HD void kat_eval(int what, const double* in, double* out)
 {
@@ -1250,6 +1250,13 @@ GI_HD void kat_eval(int what, const double* in, double* out)
     case KAT_UNIT_VEC: r = random_unit_vec(in[0], in[1]); break;
     case KAT_REFR: r = refr(ld3(in), ld3(in + 3), in[6]); break;
     case KAT_REFLECT: r = reflect(ld3(in), ld3(in + 3)); break;
+    case KAT_RNG: {   // the counter RNG (a-16): seed hi, seed lo, stream, depth, purpose, a, b -> draw, stream key hi, stream key lo
+        Rng g = rng_make(((uint64_t)(uint32_t)in[0] << 32) | (uint64_t)(uint32_t)in[1], (uint32_t)in[2]);
+        g.depth = (uint32_t)in[3];
+        r.x = rng_draw(g, (uint32_t)in[4], (uint32_t)in[5], (uint32_t)in[6]);
+        r.y = (double)(uint32_t)(g.hs >> 32); r.z = (double)(uint32_t)g.hs;
+        break;
+    }
     case KAT_SIN: r.x = sin(in[0]); break;
     case KAT_COS: r.x = cos(in[0]); break;
     case KAT_ACOS: r.x = acos(in[0]); break;

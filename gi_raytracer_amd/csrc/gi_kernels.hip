@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void k_st_compact(Scene S, CompactJob job, con
     __shared__ uint32_t part[256];
     int stream0 = 0;
     for (int q = 0; q < 3; q++) {
-        if (job.kind[q] < 0) continue;
+        if (job.kind[q] < 0) { stream0 += job.n_streams[q]; continue; }   // an unused queue still owns its streams: the next queue's begin behind them
         const unsigned int* cnt = bc + (size_t)job.kind[q] * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE;
         // exclusive prefix sums of the per-workgroup counts: thread t owns counts [t * per, t * per + per)
         const uint32_t per = (n_blocks + 255u) / 256u;
@@ -1342,7 +1342,7 @@ struct DevBuf {
 
 }  // namespace
 
-struct StreamGrids { int init = 0, trace = 0, shade = 0, shadow = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0, compact = 0; };
+struct StreamGrids { int lds_refused = 0; int init = 0, trace = 0, shade = 0, shadow = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0, compact = 0; };
 
 struct gi_ctx {
     int device = 0;
@@ -1707,10 +1707,11 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
         const void* big[] = {(const void*)k_st_trace<0, 1>, (const void*)k_st_trace<GI_FEAT_SPHERES, 1>, (const void*)k_st_trace<7, 1>,
                              (const void*)k_st_shadow<0, 0>, (const void*)k_st_shadow<GI_FEAT_SPHERES, 0>, (const void*)k_st_shadow<3, 0>, (const void*)k_st_shadow<7, 0>,
                              (const void*)k_st_shadow<0, 1>, (const void*)k_st_shadow<GI_FEAT_SPHERES, 1>, (const void*)k_st_shadow<3, 1>, (const void*)k_st_shadow<7, 1>};
-        for (const void* k : big) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsWideBoxes);
+        // a refusal here (a part with less LDS than gfx950's 160 KB per CU) would make every later launch of these kernels fail: say so by name
+        for (const void* k : big) if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsWideBoxes) != hipSuccess) g.lds_refused = (int)kLdsWideBoxes;
         const void* coop[] = {(const void*)k_st_finish<0, 1, 1>, (const void*)k_st_finish<0, 1, 2>, (const void*)k_st_finish<GI_FEAT_SPHERES, 1, 1>, (const void*)k_st_finish<GI_FEAT_SPHERES, 1, 2>,
                               (const void*)k_st_finish<3, 1, 1>, (const void*)k_st_finish<3, 1, 2>, (const void*)k_st_finish<7, 1, 1>, (const void*)k_st_finish<7, 1, 2>};
-        for (const void* k : coop) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFinishCoop);
+        for (const void* k : coop) if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFinishCoop) != hipSuccess) g.lds_refused = (int)kLdsFinishCoop;
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsWideBoxes, GI_TRACE_BLOCK);
         g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7, 1>, kLdsWideBoxes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
         g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1, 0>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
@@ -1752,6 +1753,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
                          volatile const int* cancel, int& launches)
 {
     const StreamGrids& G = stream_grids(c);
+    if (G.lds_refused) return fail(c, GI_E_HIP, "render: the device refused " + std::to_string(G.lds_refused) + " bytes of dynamic LDS per workgroup (the traversal kernels are laid out for gfx950's 160 KB per CU)");
     hipStream_t st = c->stream;
     const bool wide = c->S.wnodes != nullptr;
     PathRec* pool = c->d_pool.p;

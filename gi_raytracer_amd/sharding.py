@@ -27,20 +27,24 @@ def max_local_rows(h, stripe_h, world):
 class FrameGather:
     """Pre-allocated buffers for gathering the stripes of a w x h frame to rank 0."""
 
-    def __init__(self, torch, dist, w, h, stripe_h, rank, world, device, dtype):
+    def __init__(self, torch, dist, w, h, stripe_h, rank, world, device, dtype, always_collective=False):
+        """always_collective: issue the gather even when world == 1 (a group of one rank), so that a one-GPU box exercises the RCCL call."""
         self.torch, self.dist, self.rank, self.world, self.h = torch, dist, rank, world, h
+        self.collective = world > 1 or (always_collective and dist is not None)
+        self.n_collectives = 0
         self.rows = [stripe_rows(h, stripe_h, r, world) for r in range(world)]
         self.pad_rows = max(len(r) for r in self.rows)
         self.local = torch.zeros((self.pad_rows, w, 3), dtype=dtype, device=device)    # render target of this rank (padded)
-        self.parts = [torch.zeros_like(self.local) for _ in range(world)] if (rank == 0 and world > 1) else None
+        self.parts = [torch.zeros_like(self.local) for _ in range(world)] if (rank == 0 and self.collective) else None
         self.frame = torch.zeros((h, w, 3), dtype=dtype, device=device) if rank == 0 else None
         self.index = [torch.as_tensor(r, device=device) for r in self.rows] if rank == 0 else None
 
     def gather(self):
         """One collective: every rank's padded stripe buffer to rank 0, then rows back into frame order."""
-        if self.world == 1:
+        if not self.collective:
             self.frame[:] = self.local[: self.h]
             return self.frame
+        self.n_collectives += 1
         if self.dist.get_backend() == "gloo" and self.local.is_cuda:   # rehearsal on one device: gloo gathers host tensors
             host = self.local.cpu()
             parts = [self.torch.zeros_like(host) for _ in range(self.world)] if self.rank == 0 else None

@@ -98,8 +98,10 @@ const char* gi_last_error(const gi_ctx*);
 /* Launch kernels of this context on a caller-owned HIP stream (hipStream_t passed as void*; NULL = default stream). */
 int gi_set_stream(gi_ctx*, void* hip_stream);
 
-/* replaces: RayTracer::setScene + the tree walk of Octree::intersect/intersectSorted (include/raytracer.h:35-39,
- * include/octree.cpp:150-211,256-313) -- uploads the tables every kernel reads                                           */
+/* replaces: the scene half of RayTracer::setScene + the tree walk of Octree::intersect/intersectSorted (include/raytracer.h:35-39,
+ * include/octree.cpp:150-211,256-313) -- uploads the tables every kernel reads.  It does NOT drop the photon map (ABI change of round 2,
+ * INTEGRATION.md "ABI notes"): a caller that uploads a DIFFERENT scene calls gi_clear_photons as well -- RayTracer::setScene is the pair --
+ * or the gather keeps answering from the previous scene's photons.                                                       */
 int gi_upload_scene(gi_ctx*, const gi_scene_desc*);
 /* replaces: PhotonMap::push_back/rebuild as the source of the gather (include/photonMap.cpp:24-47).  The map outlives gi_upload_scene
  * (the reference keeps a valid map when an edited scene is rebuilt, include/raytracer.h:56-72); gi_clear_photons drops it -- RayTracer::setScene,
@@ -209,7 +211,9 @@ int gi_group_render_device(gi_group*, const gi_render_params*, int32_t stripe_h,
  * gi_kat: known answers of the scalar building blocks as the device computes them.  what: 0 fastPow(a,b), 1 fastPrecisePow(a,b)
  * (include/util.h:100-136), 2 hemisphereSample_cos(n,u,v,power), 3 sample_phong(outdir,power,sx,sy), 4 sphereCapSample_cos(n,u,v,power,frac)
  * (include/util.cpp:35-107), 5 randomUnitVec(x,y), 6 refr(inc,n,eta) (include/util.h:173-188), 7 glm::reflect(inc,n); 16..22 the libm
- * calls of the path: sin, cos, acos, asin, atan2(a,b), pow(a,b), sqrt.  in [n][in_stride] (arguments in the order given), out3 [n][3].  */
+ * calls of the path: sin, cos, acos, asin, atan2(a,b), pow(a,b), sqrt.  8 = the counter RNG that stands in for drand() (include/util.h:52-80;
+ * DESIGN.md "RNG contract"): in = seed high 32 bits, seed low 32 bits, stream, depth, purpose, a, b (integers carried in doubles),
+ * out = the draw, the stream key's high and low 32 bits.  in [n][in_stride] (arguments in the order given), out3 [n][3].  */
 int gi_debug_leaf_order(gi_ctx*, int32_t n, const double* rays, int32_t cap, int32_t* leaf_out, int32_t* n_out);
 int gi_kat(gi_ctx*, int32_t what, int32_t n, const double* in, int32_t in_stride, double* out3);
 

@@ -73,6 +73,40 @@ def check_kats(rt, golden):
     assert rt.kat("reflect", r[:, :6]).tobytes() == np.ascontiguousarray(r[:, 10:13]).tobytes()
 
 
+def check_rng(rt):
+    """a-16: the counter RNG that stands in for drand() (include/util.h:52-80 is a sequential xorshift64* chain a parallel device cannot replay;
+    DESIGN.md "RNG contract"), as the device evaluates it through gi_kat, against the oracle's on a lattice of (seed, stream, depth, purpose, a, b):
+    every draw bit-exact (integer mixing + one exact scaling), and the stream key too -- a regression in the key mixing shows here, not as a frame."""
+    L = ol.lib()
+    rs = np.random.RandomState(16)
+    seeds = [0, 1, gi.DEFAULT_SEED, 0xffffffffffffffff, 0x5048544f4e5eed00 ^ gi.DEFAULT_SEED] + [int(v) for v in rs.randint(0, 2**63, 6, dtype=np.int64)]
+    streams = [0, 1, 2, 1146617855, 2**31 - 1, 2**31, 2**32 - 1] + [int(v) for v in rs.randint(0, 2**32, 6, dtype=np.int64)]
+    depths = [0, 1, 2, 3, 10, 63, 64, 65]
+    purposes = [0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 17, 18, 19, 20, 21, 22, 1 | (1 << 8), 2 | (3 << 8), 7 | (255 << 8)]
+    ab = [(0, 0), (1, 0), (0, 1), (1557, 2191), (2**32 - 1, 2**32 - 1), (17, 2**31)] + [(int(a), int(b)) for a, b in rs.randint(0, 2**32, (6, 2), dtype=np.int64)]
+    rows = [(sd, st, d, pu, a, b) for sd in seeds for st in streams for d in depths for pu in purposes for (a, b) in ab[:4]]
+    rows += [(seeds[2], st, 1, pu, a, b) for st in streams for pu in purposes for (a, b) in ab[4:]]
+    arg = np.array([[sd >> 32, sd & 0xffffffff, st, d, pu, a, b] for (sd, st, d, pu, a, b) in rows], np.float64)
+    got = rt.kat("rng", arg)
+    want = np.array([L.gio_counter_rand(sd, st, d, pu, a, b) for (sd, st, d, pu, a, b) in rows])
+    assert got[:, 0].tobytes() == want.tobytes()
+    assert ((got[:, 0] >= 0) & (got[:, 0] < 1)).all()
+    # distinct keys of one seed give distinct draws (across seeds the contract lets (seed, stream) and (seed + golden ratio, stream - 1) coincide)
+    for sd in seeds:
+        d = got[[r[0] == sd for r in rows], 0]
+        assert len(np.unique(d)) == len(d)
+    # the stream key alone (what rng_make leaves in the lane's registers): draws of one stream at depth 0, purpose 0 agree => keys agree; and
+    # distinct streams of one seed have distinct keys
+    keys = got[:, 1] * 2.0 ** 32 + got[:, 2]
+    first = {}
+    for r, k in zip(rows, keys):
+        assert first.setdefault((r[0], r[1]), k) == k
+    for sd in seeds:
+        ks = [k for (s_, _), k in first.items() if s_ == sd]
+        assert len(set(ks)) == len(ks)
+    return len(rows)
+
+
 def check_leaf_order(rt, fx, set_wide=None):
     """a-4: the leaves the device walk meets for a ray, in order, against Octree::intersectSorted's t0-sorted list of the reference
     (leaforder_* of the scene fixtures).  The reference orders leaves with equal t0 by insertion (pre-order DFS, include/octree.cpp:285-313);

@@ -27,6 +27,11 @@ def test_counter_rng_matches_oracle():
         assert L.gio_counter_rand(a[0] * 7919, a[1], a[2] % 70, a[3] % 4096, a[4], a[5]) == E.emul_rng(a[0] * 7919, a[1], a[2] % 70, a[3] % 4096, a[4], a[5])
 
 
+def test_counter_rng_known_answers_through_kat():
+    """SURVEY 8 a-16 on the CPU build: the same lattice the GPU test runs through gi_kat (what = 8)."""
+    assert pc.check_rng(el.EmulRayTracer()) > 10000
+
+
 def test_trace_matches_reference_table(setup):
     pc.check_trace_table(setup[2], setup[3])
 

@@ -47,6 +47,11 @@ def test_sampler_known_answers(rt0, golden):
     pc.check_kats(rt0, golden)
 
 
+def test_counter_rng_known_answers(rt0):
+    """rng_draw / rng_make on the device (gi_kat what = 8) against the oracle's counter RNG, bit-exact on a lattice of keys."""
+    assert pc.check_rng(rt0) > 10000
+
+
 def test_visible_matches_reference_table(setup):
     pc.check_visible_table(setup[2], setup[3])
 
@@ -227,9 +232,15 @@ def test_two_lights_match_oracle(with_glass):
     assert float(img.mean()) > 1e-3      # the lights do reach the scene
 
 
-def test_wavefront_small_pool_many_rounds(setup):
-    """Few path slots -> many rounds of few samples each: the same frame as with one big round."""
+@pytest.mark.parametrize("with_photons", [False, True])
+def test_wavefront_small_pool_many_rounds(setup, with_photons):
+    """Few path slots -> many rounds of few samples each: the same frame as with one big round.  With and without a photon map: without one the
+    shade stage's compaction job has an unused (gather) queue in the middle, and the free list behind it is what the refills draw from."""
     name, scene, rt, fx = setup
+    if with_photons and scene.desc().n_light > 0:
+        rt.tracePhotons(3000)
+    else:
+        rt.clear_photons()
     a = rt.run(40, 30, min_samples=6, max_samples=6)
     rt.set_pool_slots(40 * 32 * 2)      # 2 paths per (padded) pixel
     try:
@@ -240,6 +251,37 @@ def test_wavefront_small_pool_many_rounds(setup):
         rt.set_pool_slots(1 << 30)
         rt.set_render_mode("wavefront")
     assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("name", ["cornell", "caustics", "teapot"])
+def test_pool_refills_without_photon_map(name):
+    """Path regeneration from the free list with NO photon map loaded (BASELINE config 2's state, but with a pool smaller than the frame, as on a
+    4K x 256 spp frame or on ranks that share a device): slots freed by the shade stage must reach the next pass's free list.  Frames with pools of
+    1/3, 1/7 and 1/20 of the samples equal the whole-frame-in-flight frame and the synchronous-rounds frame, bit for bit."""
+    scene = pc.load_scene(name)
+    rt = gi.RayTracer(0).setScene(scene)          # setScene drops any photon map (gi_upload_scene + gi_clear_photons)
+    w, h, spp = 64, 48, 12
+    a = rt.run(w, h, min_samples=spp, max_samples=spp)
+    assert a.mean() > 1e-3
+    try:
+        for div in (3, 7, 20):
+            rt.set_pool_slots(max(64, w * h * spp // div))
+            assert np.array_equal(a.view(np.uint64), rt.run(w, h, min_samples=spp, max_samples=spp).view(np.uint64)), div
+        rt.set_render_mode("rounds")
+        assert np.array_equal(a.view(np.uint64), rt.run(w, h, min_samples=spp, max_samples=spp).view(np.uint64))
+    finally:
+        rt.set_pool_slots(1 << 30)
+        rt.set_render_mode("wavefront")
+    # and the same with a map loaded afterwards, then dropped again: the photon-free job is back
+    rt.tracePhotons(2000)
+    b = rt.run(w, h, min_samples=spp, max_samples=spp)
+    rt.clear_photons()
+    rt.set_pool_slots(max(64, w * h * spp // 5))
+    try:
+        assert np.array_equal(a.view(np.uint64), rt.run(w, h, min_samples=spp, max_samples=spp).view(np.uint64))
+    finally:
+        rt.set_pool_slots(1 << 30)
+    assert b.shape == a.shape
 
 
 def test_gather_resolves_float_key_ties_exactly():
@@ -365,6 +407,44 @@ def test_full_size_properties(name, w, h, spp, photons):
         o.set_photons(ph).build_photon_map()
         ref = o.render(w, h, spp, y0=h // 2, y1=h // 2 + 4)["lin"][h // 2:h // 2 + 4]
         assert np.sqrt(((a[h // 2:h // 2 + 4] - ref) ** 2).mean()) < 1e-9
+
+
+@pytest.mark.parametrize("name,w,h,spp,photons,rows", [
+    ("cornell", 512, 512, 64, 0, (101, 256, 380, 490)),            # BASELINE config 2
+    ("caustics", 1920, 1080, 256, 200000, (400, 700)),             # BASELINE config 3 (the benchmark frame): 2 rows = 983 k samples on the CPU
+    ("teapot", 1920, 1080, 256, 200000, (620, 900)),               # BASELINE config 4 (one GPU's view of the frame; the 8-rank stripes are test_full_size_properties')
+])
+def test_baseline_configs_at_their_own_spp_match_oracle(name, w, h, spp, photons, rows):
+    """BASELINE.json configs 2, 3, 4 rendered ONCE at their own frame size, sample count and photon count; full-width rows spread over the frame
+    against the oracle (<= 1 M samples of CPU work each).  Contract: RMSE < 1e-4 on linear radiance (north_star); asserted two orders below it,
+    the measured value is printed (config 4 refracts through the glass teapot: a handful of paths take another branch, DESIGN.md "Numerics")."""
+    scene = pc.load_scene(name)
+    rt = gi.RayTracer(0).setScene(scene)
+    o = pc.oracle_for(scene)
+    ph = np.zeros((0, 9))
+    if photons:
+        ph, _ = rt.tracePhotons(photons)
+        assert len(ph) > 0.5 * photons
+    o.set_photons(ph).build_photon_map()
+    img, nspp = rt.run(w, h, min_samples=spp, max_samples=spp, want_spp=True)
+    assert (nspp == spp).all() and np.isfinite(img).all()
+    rows = np.array(rows, np.int32)
+    ref, _ = o.render_rows(w, h, rows, spp, rt.seed, 16)
+    d = img[rows] - ref[rows]
+    rmse = float(np.sqrt((d ** 2).mean()))
+    print(f"{name} {w}x{h} {spp} spp: rmse vs oracle on rows {rows.tolist()} = {rmse:.3e}, max |diff| {np.abs(d).max():.3e}, mean radiance {img.mean():.6f}")
+    assert rmse < (1e-6 if name == "teapot" else 1e-8), rmse
+    assert np.median(np.abs(d)) < 1e-12
+
+
+def test_textured_glass_scene_at_256_spp_is_inside_the_contract():
+    """scenes/textures/cornell_tex.scn (glass teapot between bright textured walls: the scene where a diverted refraction chain costs most) at the
+    sample count the contract is quoted at: RMSE < 1e-4 asserted (at 8 spp the same frame measures 2.3e-4, at 64 spp 4.2e-5)."""
+    scene = pc.load_scene("cornell_tex")
+    rt = gi.RayTracer(0).setScene(scene)
+    rmse, img, ref = pc.check_render(rt, scene, 96, 54, 256, 5000, tol=1e-4)
+    print("cornell_tex 96x54 256 spp rmse", rmse, "pixels off", (np.abs(img - ref).max(axis=2) > 1e-9).mean())
+    assert np.median(np.abs(img - ref)) < 1e-12
 
 
 def test_eight_bit_frame_matches_oracle():
@@ -539,3 +619,48 @@ def test_headless_cli_writes_the_display_frame(tmp_path):
     rt.tracePhotons(3000)
     lin = rt.run(96, 54, f64=False, min_samples=4, max_samples=8)
     assert np.array_equal(img, gi.to_rgb8(lin)) and "Msamples/s" in r.stdout
+
+
+_RCCL_CHILD = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
+import numpy as np, torch, torch.distributed as dist
+import gi_raytracer_amd as gi, parity_checks as pc
+from gi_raytracer_amd.sharding import STRIPE_H, FrameGather
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)            # nccl IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+scene = pc.load_scene("caustics"); rt = gi.RayTracer(0).setScene(scene); rt.set_stream(torch.cuda.current_stream().cuda_stream)
+rt.tracePhotonsOnDevice(3000)
+w, h, spp = 96, 70, 4
+p = rt.params(w, h, stripe_h=STRIPE_H, rank=0, world=1, min_samples=spp, max_samples=spp)
+fg = FrameGather(torch, dist, w, h, STRIPE_H, 0, 1, dev, torch.float32, always_collective=True)
+rt.run_device(p, fg.local.data_ptr(), f64=False)
+frame = fg.gather()                                                                 # dist.gather of device tensors over RCCL
+dist.barrier(); torch.cuda.synchronize()
+tt = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX)   # bench.py's max-over-ranks of its timings
+ref = rt.run(w, h, f64=False, min_samples=spp, max_samples=spp)
+print(json.dumps({"equal": bool(np.array_equal(frame.cpu().numpy(), ref)), "mean": float(ref.mean()), "tt": tt.tolist(), "collectives": fg.n_collectives}))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_gather_path_runs_on_one_rank(tmp_path):
+    """The RCCL branch of the multi-GPU path (bench.py: init_process_group("nccl", device_id=...), sharding.FrameGather.gather on device tensors,
+    the all-reduce of the timings) executed once on this one-GPU box: world_size 1, in a fresh child process that initialises its group before
+    any other GPU work.  The gathered frame equals the plain single-GPU frame."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    script = tmp_path / "rccl_child.py"
+    script.write_text(_RCCL_CHILD)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script), pc.ROOT, str(port)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["equal"] and out["mean"] > 1e-3 and out["tt"] == [1.5, 2.5] and out["collectives"] == 1
