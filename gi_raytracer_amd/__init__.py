@@ -61,7 +61,7 @@ _LIB = None
 # every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
-    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_trace", "gi_visible",
+    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_get_stream_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
     "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
@@ -98,6 +98,7 @@ def lib():
     L.gi_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.gi_set_counters.argtypes = [vp, C.c_int]
     L.gi_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.gi_get_stream_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gi_trace.argtypes = [vp, C.c_int32, _dp, _ip, _ip, _dp]
     L.gi_visible.argtypes = [vp, C.c_int32, _dp, _ip]
     L.gi_gather.argtypes = [vp, C.c_int32, _dp, _dp, _ip]
@@ -542,8 +543,20 @@ class RayTracer:
         self._check(self.L.gi_last_stage_ms(self.h, out), "last_stage_ms")
         return dict(zip(self.STAGES, [float(v) for v in out]))
 
-    def set_counters(self, on):
-        self.L.gi_set_counters(self.h, 1 if on else 0)
+    def set_counters(self, mode):
+        """0 / False: off; 1 / True: the reference's visits (megakernel, per-node walk); 2 or "stream": what the streaming kernels execute."""
+        m = {"stream": 2, True: 1, False: 0}.get(mode, mode)
+        self._check(self.L.gi_set_counters(self.h, int(m)), "set_counters")
+
+    STREAM_COUNTERS = ("trace_walks", "trace_records", "trace_child_boxes", "trace_content_boxes", "trace_leaves", "trace_tris", "trace_rays",
+                       "shadow_walks", "shadow_records", "shadow_child_boxes", "shadow_content_boxes", "shadow_leaves", "shadow_tris", "shadow_rays",
+                       "gather_queries", "gather_candidates", "shaded")
+
+    def stream_counters(self):
+        """gi_get_stream_counters: the executed work of the last frame rendered with set_counters("stream"), as a dict."""
+        out = (C.c_int64 * 17)()
+        self._check(self.L.gi_get_stream_counters(self.h, out), "get_stream_counters")
+        return dict(zip(self.STREAM_COUNTERS, [int(v) for v in out]))
 
     def counters(self):
         out = (C.c_int64 * 8)()

@@ -611,13 +611,14 @@ GI_HD WRay wray_make(const Ray& r)
 // same results by construction (frames with and without culling are compared bit for bit, gi_set_content_culling).  What it saves is the
 // visits that could not have mattered: in the benchmark 96 % of the reflected rays leave the scene, and their walks shrink to a few nodes.
 // m: candidate children in the ray's order (bit k = slot k ^ a); returns m without the children the ray cannot hit anything in.
-GI_HD uint32_t content_cull(const float* cboxes, const uint32_t* cuse, int32_t node, uint32_t m, const Ray& r, const WRay& wr)
+GI_HD uint32_t content_cull(const float* cboxes, const uint32_t* cuse, int32_t node, uint32_t m, const Ray& r, const WRay& wr, uint32_t* n_tested = nullptr)
 {
     uint32_t u = cuse[node];
     if (wr.a & 1) u = ((u & 0x55u) << 1) | ((u >> 1) & 0x55u);      // slot bits -> the ray's order, as wide_hits does
     if (wr.a & 2) u = ((u & 0x33u) << 2) | ((u >> 2) & 0x33u);
     if (wr.a & 4) u = ((u & 0x0fu) << 4) | ((u >> 4) & 0x0fu);
     uint32_t todo = m & u;
+    if (n_tested) *n_tested = (uint32_t)__builtin_popcount(todo);
     const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
     while (todo) {
         const int kk = __builtin_ctz(todo);
@@ -688,7 +689,19 @@ GI_HD void wide_leaf_box(const WNode* w, int slot, double* lmin, double* lmax)  
 #define GI_DIV(W, k) do { } while (0)
 #define GI_DIVN(W, k, n) do { } while (0)
 #endif
-struct GlobalWide {
+// Work a walk actually executes (gi_set_counters(ctx, 2): the streaming kernels count it per lane): walks begun (= tests of the root box), wide
+// records visited, child boxes tested from them (one per existing child: together with the root tests these are the reference's
+// BoundingBox::intersect calls when nothing is culled), content boxes tested, non-empty leaves met, entity tests.  A record source that does
+// not count compiles the ticks to nothing.
+struct WalkCnt { uint32_t walks, nodes, child_boxes, cull_tests, leaves, tris; };
+struct NoWalkCnt {
+    GI_HDM void tick_walk() const {}
+    GI_HDM void tick_node(uint32_t) const {}
+    GI_HDM void tick_cull(uint32_t) const {}
+    GI_HDM void tick_leaf() const {}
+    GI_HDM void tick_tri() const {}
+};
+struct GlobalWide : NoWalkCnt {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
     const WNode* g;
@@ -729,7 +742,7 @@ GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr
         if (cb < 0) {
             GI_DIV(W, 0);
             wwalk_push(k, ca);
-            k.m = W.with(ca, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+            k.m = W.with(ca, [&](const WNode* w) { W.tick_node(w->exists); return wide_hits(w, ray, wr, tmin0, tmax0); });
             if (k.m) k.m = W.cull(ca, k.m, ray, wr);
             continue;
         }
@@ -756,7 +769,7 @@ GI_HD int wwalk_turn(const WN& W, WWalk& k, const Ray& ray, const WRay& wr, doub
     if (cb < 0) {
         GI_DIV(W, 0);
         wwalk_push(k, ca);
-        k.m = W.with(ca, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+        k.m = W.with(ca, [&](const WNode* w) { W.tick_node(w->exists); return wide_hits(w, ray, wr, tmin0, tmax0); });
         if (k.m) k.m = W.cull(ca, k.m, ray, wr);
         return WALK_MOVED;
     }
@@ -767,8 +780,9 @@ template <class WN>
 GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0)
 {
     k.node = 0; k.m = 0; k.lo = 0; k.hi = 0;
+    W.tick_walk();
     if (!box_hit(S.root_bmin, S.root_bmax, ray, tmin0, tmax0)) return false;
-    k.m = W.with(0, [&](const WNode* w) { return wide_hits(w, ray, wr, tmin0, tmax0); });
+    k.m = W.with(0, [&](const WNode* w) { W.tick_node(w->exists); return wide_hits(w, ray, wr, tmin0, tmax0); });
     if (k.m) k.m = W.cull(0, k.m, ray, wr);
     return true;
 }
@@ -796,11 +810,13 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
     int lslot = 0;
     if (!wwalk_next_leaf(W, t.k, ray, t.wr, 0.0, INFINITY, lnode, lslot, first, cnt)) return false;
     GI_DIV(W, 2);
+    W.tick_leaf();
     bool term = false;
     auto test = [&](const LeafTri& g) {
         const int32_t ti = g.tri;
         double u, v;
         V3 hp;
+        W.tick_tri();
         if (!ent_hit<FEAT>(g, g.matflags, ray, u, v, hp)) return;
         if (FEAT & GI_FEAT_TEX) ent_uv(S, g, g.matflags, ti, u, v, hp, t.cu, t.cv);
         if (!(g.matflags & 2u)) {
@@ -862,10 +878,12 @@ template <int FEAT, class WN>
 GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, int32_t lnode, int lslot, int32_t first, int32_t cnt)
 {
     GI_DIV(W, 2);
+    W.tick_leaf();
     auto blocks = [&](const LeafTri& g) -> bool {
         const int32_t ti = g.tri;
         double u, vv;
         V3 hp;
+        W.tick_tri();
         if (!ent_hit<FEAT>(g, g.matflags, ray, u, vv, hp)) return false;
         if (!(g.matflags & 2u)) {
             const Mat& m = S.mats[g.matflags >> 3];

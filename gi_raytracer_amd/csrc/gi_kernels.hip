@@ -129,9 +129,18 @@ __device__ __forceinline__ LdsNodes stage_nodes_in_lds(const Scene& S)
 #define GI_LDS_BOXES_BYTES(cap) (GI_LDS_CUSE_OFF(cap) + (cap) * 4)
 #define GI_LDS_BIG_CNT_OFF GI_LDS_CNT_OFF(GI_LDS_WNODES_BIG)
 #define GI_LDS_WIDE_BOXES_BYTES GI_LDS_BOXES_BYTES(GI_LDS_WNODES_BIG)
-struct LdsWide {
+template <bool COUNT>
+struct LdsWideT {
     static constexpr bool kWide = true;
     static constexpr bool kCoop = false;
+    static constexpr bool kCount = COUNT;
+    // executed-work counters of this lane (gi_set_counters(ctx, 2)); an instance that does not count never touches them, and they are gone
+    mutable WalkCnt wc = {0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ void tick_walk() const { if constexpr (COUNT) wc.walks++; }
+    __device__ __forceinline__ void tick_node(uint32_t exists) const { if constexpr (COUNT) { wc.nodes++; wc.child_boxes += (uint32_t)__builtin_popcount(exists & 0xffu); } }
+    __device__ __forceinline__ void tick_cull(uint32_t n) const { if constexpr (COUNT) wc.cull_tests += n; }
+    __device__ __forceinline__ void tick_leaf() const { if constexpr (COUNT) wc.leaves++; }
+    __device__ __forceinline__ void tick_tri() const { if constexpr (COUNT) wc.tris++; }
     const WNode* g;
     const float* cboxes;      // content boxes of the children (gi_device.h: content_cull), read through L1 / L2; null = no culling
     const uint32_t* cuse;
@@ -150,13 +159,18 @@ struct LdsWide {
     __device__ __forceinline__ uint32_t cull(int32_t node, uint32_t m, const Ray& r, const WRay& wr) const
     {
         if (!cboxes) return m;
-        if (node < n_lc) return content_cull(reinterpret_cast<const float*>(gi_dyn_lds + box_off), reinterpret_cast<const uint32_t*>(gi_dyn_lds + use_off), node, m, r, wr);
-        return content_cull(cboxes, cuse, node, m, r, wr);
+        uint32_t nt = 0;
+        uint32_t* const ntp = COUNT ? &nt : nullptr;
+        const uint32_t res = node < n_lc ? content_cull(reinterpret_cast<const float*>(gi_dyn_lds + box_off), reinterpret_cast<const uint32_t*>(gi_dyn_lds + use_off), node, m, r, wr, ntp)
+                                         : content_cull(cboxes, cuse, node, m, r, wr, ntp);
+        tick_cull(nt);
+        return res;
     }
 };
+typedef LdsWideT<false> LdsWide;
 #ifdef GI_EXP_DIV
 __device__ unsigned long long g_div[64 * 16 * 2];   // [workgroup & 63][kernel][counter]
-__device__ __forceinline__ void div_flush(const LdsWide& N, int kernel)
+template <class LW> __device__ __forceinline__ void div_flush(const LW& N, int kernel)
 {
     for (int k = 0; k < 8; k++) {
         unsigned long long v = N.ds[k];
@@ -178,9 +192,10 @@ extern "C" int gi_debug_div(unsigned long long* out, int reset)
 }
 #endif
 template <int G> struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; static constexpr int kGroup = G; };   // the same records, one ray per group of G lanes (gi_device.h: trace_wide_coop)
-__device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S, bool with_boxes = false, int boxes_cap = GI_LDS_WNODES_BIG)
+template <bool COUNT = false>
+__device__ __forceinline__ LdsWideT<COUNT> stage_wide_in_lds(const Scene& S, bool with_boxes = false, int boxes_cap = GI_LDS_WNODES_BIG)
 {
-    LdsWide N;
+    LdsWideT<COUNT> N;
     N.g = S.wnodes;
     N.cboxes = S.cboxes; N.cuse = S.cuse;
     const int cap = with_boxes ? boxes_cap : GI_LDS_WNODES;
@@ -200,11 +215,24 @@ __device__ __forceinline__ LdsWide stage_wide_in_lds(const Scene& S, bool with_b
     __syncthreads();
     return N;
 }
-template <int WIDE> struct LdsSrc;
-template <> struct LdsSrc<0> { typedef LdsNodes type; static __device__ __forceinline__ LdsNodes stage(const Scene& S) { return stage_nodes_in_lds(S); }
+template <int WIDE, bool COUNT = false> struct LdsSrc;
+template <bool COUNT> struct LdsSrc<0, COUNT> { typedef LdsNodes type; static __device__ __forceinline__ LdsNodes stage(const Scene& S) { return stage_nodes_in_lds(S); }
                          static __device__ __forceinline__ LdsNodes stage_with_boxes(const Scene& S) { return stage_nodes_in_lds(S); } };
-template <> struct LdsSrc<1> { typedef LdsWide type; static __device__ __forceinline__ LdsWide stage(const Scene& S) { return stage_wide_in_lds(S); }
-                         static __device__ __forceinline__ LdsWide stage_with_boxes(const Scene& S) { return stage_wide_in_lds(S, true); } };
+template <bool COUNT> struct LdsSrc<1, COUNT> { typedef LdsWideT<COUNT> type; static __device__ __forceinline__ type stage(const Scene& S) { return stage_wide_in_lds<COUNT>(S); }
+                         static __device__ __forceinline__ type stage_with_boxes(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true); } };
+// what the streaming kernels executed in one frame (gi_get_stream_counters): per-lane WalkCnt sums of k_st_trace and k_st_shadow, the rays handed
+// to each, the gather's queries and the candidates they scanned
+struct StreamCounters { unsigned long long trace[6], trace_rays, shadow[6], shadow_rays, gather_queries, gather_cand; };
+__device__ __forceinline__ void flush_u64(unsigned long long* dst, unsigned long long v)
+{
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63u) == 0u && v) atomicAdd(dst, v);
+}
+__device__ __forceinline__ void flush_walk_cnt(unsigned long long* dst6, const WalkCnt& w)
+{
+    flush_u64(dst6 + 0, w.walks); flush_u64(dst6 + 1, w.nodes); flush_u64(dst6 + 2, w.child_boxes);
+    flush_u64(dst6 + 3, w.cull_tests); flush_u64(dst6 + 4, w.leaves); flush_u64(dst6 + 5, w.tris);
+}
 
 // ================================================================================================= wavefront pipeline
 // The frame is rendered in rounds.  In a round every pixel that still wants samples (adaptive loop of RayTracer::run,
@@ -524,18 +552,20 @@ struct GenArgs {
 // the others walk on -- a wave no longer runs at the pace of its longest ray with the other lanes switched off (closed scenes: a third
 // of the lanes were active per leaf step).  Waves of new paths (neighbouring pixels, leaves shared through the scalar cache) stay in
 // lockstep: refill_min = 64 for them.  The workgroup's items are those of the grid-stride loop, so seg_start still bounds its output.
-template <int FEAT, int WIDE>
+template <int FEAT, int WIDE, bool COUNT = false>
 __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, unsigned long long* slot_sample, unsigned long long sample0,
                                                        GenArgs g, const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, unsigned int* bc, uint32_t* segs,
-                                                       uint32_t* q_shade, uint32_t* q_free, double* lbuf, uint32_t refill_min)
+                                                       uint32_t* q_shade, uint32_t* q_free, double* lbuf, uint32_t refill_min, StreamCounters* sc)
 {
+    static_assert(!COUNT || WIDE != 0, "the executed-work counters belong to the wide walk");
     // wide instances: next unfetched item of this workgroup, in its own numbering; lives in the 128 bytes the 292 wide records leave of the 64 KB
     static_assert(sizeof(WNode) == 224 && GI_LDS_WIDE_BOXES_BYTES <= 160 * 1024, "LDS layout of the wide trace / shadow kernels");
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + GI_LDS_BIG_CNT_OFF);
     if (WIDE != 0 && threadIdx.x == 0) *s_next = 0u;
-    const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage_with_boxes(S);   // ends with a barrier
+    const typename LdsSrc<WIDE, COUNT>::type N = LdsSrc<WIDE, COUNT>::stage_with_boxes(S);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = g.n_gen + n_a + n_b;
+    uint32_t n_rays = 0;   // COUNT: items this lane took
     const uint32_t cs = WIDE != 0 ? (uint32_t)GI_TRACE_CHUNK : blockDim.x;
     const uint32_t seg = seg_start(blockIdx.x, n_in, gridDim.x, cs);   // this workgroup's segment of the staging queues
     if (threadIdx.x == 0) segs[blockIdx.x] = seg;
@@ -624,6 +654,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                         const uint32_t i = ((u / bs) * gridDim.x + blockIdx.x) * bs + u % bs;
                         if (u < total && i < n_in) {
                             item = i;
+                            if constexpr (COUNT) n_rays++;
                             fetch(i, slot, ray, stream, depth);
                             rng = rng_make(seed, stream);
                             rng.depth = (uint32_t)depth;
@@ -665,6 +696,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
 #ifdef GI_EXP_DIV
     if constexpr (WIDE != 0) div_flush(N, 0);
 #endif
+    if constexpr (COUNT) { flush_walk_cnt(sc->trace, N.wc); flush_u64(&sc->trace_rays, n_rays); }
 }
 
 // the walk-free instance fits its registers at 2 waves per SIMD without a spill and runs faster that way (128.. VGPRs, 4 waves: 260 B of
@@ -744,16 +776,17 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
 // ran with 15-40 % of the lanes (a wave waited for its longest segment, under the register pressure of the whole shade stage).
 // MULTI: several lights -- the reference keeps the share of the LAST visible light of a vertex, so a lane asks the item's queries from the last light
 // down and stops at the first visible one (the medium's answer is then needed at the end of each walk, not only when the lane retires).
-template <int FEAT, int MULTI>
-__global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min)
+template <int FEAT, int MULTI, bool COUNT = false>
+__global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min, StreamCounters* sc)
 {
     const uint32_t nl = MULTI ? (uint32_t)S.n_light : 1u;
     uint32_t li = 0;   // the light this lane's walk is about
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + GI_LDS_BIG_CNT_OFF);
     if (threadIdx.x == 0) *s_next = 0u;
-    const LdsWide N = stage_wide_in_lds(S, true);   // ends with a barrier
+    const LdsWideT<COUNT> N = stage_wide_in_lds<COUNT>(S, true);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = ctl->n_shade, bs = (uint32_t)GI_TRACE_CHUNK;
+    uint32_t n_rays = 0;   // COUNT: shadow segments this lane walked
     const uint32_t total = seg_start(blockIdx.x + 1, n_in, gridDim.x, bs) - seg_start(blockIdx.x, n_in, gridDim.x, bs);
     bool walking = false, pend = false, blocked = false;
     uint32_t item = 0;
@@ -798,6 +831,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
                         li = nl - 1u;
                         const ShadowQ& e = shq[(size_t)i * nl + li];
                         item = i;
+                        if constexpr (COUNT) n_rays++;
                         const V3 dir = ld3(e.dir);
                         ray = make_ray(ld3(e.o), dir);
                         mt = len2(dir);
@@ -833,6 +867,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
         if constexpr (MULTI != 0) {   // this light is hidden: on to the one before it, in the same lane
             while (pend && blocked && li > 0u) {
                 li--;
+                if constexpr (COUNT) n_rays++;
                 const ShadowQ& e = shq[(size_t)item * nl + li];
                 const V3 dir = ld3(e.dir);
                 ray = make_ray(ld3(e.o), dir);
@@ -847,6 +882,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
 #ifdef GI_EXP_DIV
     div_flush(N, 1);
 #endif
+    if constexpr (COUNT) { flush_walk_cnt(sc->shadow, N.wc); flush_u64(&sc->shadow_rays, n_rays); }
 }
 
 // Closes the gaps between the workgroups' segments of up to three staging queues (one launch per producer kernel).  Stream k copies
@@ -954,9 +990,11 @@ __device__ __forceinline__ void kmerge32(float (&v)[32])   // bitonic sequence -
             if (l > i) kce(v[i], v[l]);
         }
 }
+template <bool COUNT>
 __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in,
-                                                                         const unsigned long long* slot_sample, unsigned long long sample0, double* lbuf)
+                                                                         const unsigned long long* slot_sample, unsigned long long sample0, double* lbuf, StreamCounters* sc)
 {
+    unsigned long long n_q = 0, n_c = 0;   // COUNT: queries of this lane, candidates they scanned (a leaf's whole candidate list per query, as PhotonMap::getInRange returns it)
     // 8 KB of LDS per wave: the staged candidates of the cooperative path (64 x 9 doubles) or the float heaps of the per-lane walk (32 x 64),
     // never both at once -- a wave is in one of the two, and the tie pass runs after the last candidate was read
     __shared__ __align__(16) float lds[GI_GATHER_K * GI_BLOCK];
@@ -980,12 +1018,17 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
         const uint32_t leaf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
         const bool has_leaf = valid && leaf < (uint32_t)S.n_pnode;
         const bool uniform = __ballot(valid && leaf != leaf0) == 0ull && leaf0 < (uint32_t)S.n_pnode;
+        if constexpr (COUNT) { if (valid) n_q++; }
         if (!uniform) {
-            if (has_leaf) stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap, 64, lbuf + (slot_sample[vals[i]] - sample0) * 3);
+            if (has_leaf) {
+                if constexpr (COUNT) n_c += (unsigned long long)S.pnodes[leaf].u.lf.nb_photons;
+                stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap, 64, lbuf + (slot_sample[vals[i]] - sample0) * 3);
+            }
             continue;
         }
         const PNode& lf = S.pnodes[leaf0];
         const int ncand = lf.u.lf.nb_photons;
+        if constexpr (COUNT) { if (valid) n_c += (unsigned long long)ncand; }
         if (ncand == 0) continue;
         const PRange* ranges = S.pranges + lf.nb_off;
         GatherAcc a;
@@ -1087,6 +1130,7 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
             Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
         }
     }
+    if constexpr (COUNT) { flush_u64(&sc->gather_queries, n_q); flush_u64(&sc->gather_cand, n_c); }
 }
 
 // the last stragglers of a chunk (paths bouncing between specular surfaces up to MAX_DEPTH), finished without one nearly
@@ -1421,7 +1465,10 @@ struct gi_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0;
     int last_launches = 0;
-    bool count_enabled = false;
+    bool count_enabled = false;       // gi_set_counters(ctx, 1): the megakernel counts the reference's visits (per-node walk)
+    bool count_stream = false;        // gi_set_counters(ctx, 2): the streaming kernels count what they execute (StreamCounters)
+    DevBuf<StreamCounters> d_stream_cnt;
+    unsigned long long stream_shaded = 0;   // shaded hits of the last counted frame (sum of the shade queues' lengths)
     Counters last_counters{};
     int n_cu = 256;
 };
@@ -1704,7 +1751,8 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
     StreamGrids& g = c->grids;
     if (!g.trace) {
         // more than 64 KB of dynamic LDS has to be asked for, per kernel (and per device: the attribute belongs to the loaded code object)
-        const void* big[] = {(const void*)k_st_trace<0, 1>, (const void*)k_st_trace<GI_FEAT_SPHERES, 1>, (const void*)k_st_trace<7, 1>,
+        const void* big[] = {(const void*)k_st_trace<0, 1, true>, (const void*)k_st_shadow<0, 0, true>, (const void*)k_st_shadow<0, 1, true>,
+                             (const void*)k_st_trace<0, 1>, (const void*)k_st_trace<GI_FEAT_SPHERES, 1>, (const void*)k_st_trace<7, 1>,
                              (const void*)k_st_shadow<0, 0>, (const void*)k_st_shadow<GI_FEAT_SPHERES, 0>, (const void*)k_st_shadow<3, 0>, (const void*)k_st_shadow<7, 0>,
                              (const void*)k_st_shadow<0, 1>, (const void*)k_st_shadow<GI_FEAT_SPHERES, 1>, (const void*)k_st_shadow<3, 1>, (const void*)k_st_shadow<7, 1>};
         // a refusal here (a part with less LDS than gfx950's 160 KB per CU) would make every later launch of these kernels fail: say so by name
@@ -1713,7 +1761,7 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
                               (const void*)k_st_finish<3, 1, 1>, (const void*)k_st_finish<3, 1, 2>, (const void*)k_st_finish<7, 1, 1>, (const void*)k_st_finish<7, 1, 2>};
         for (const void* k : coop) if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsFinishCoop) != hipSuccess) g.lds_refused = (int)kLdsFinishCoop;
         g.init = grid_for(c, (const void*)k_wf_init); g.trace = grid_for(c, (const void*)k_st_trace<7, 1>, kLdsWideBoxes, GI_TRACE_BLOCK);
-        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7, 1>, kLdsWideBoxes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather); g.accum = grid_for(c, (const void*)k_st_accum);
+        g.shade = grid_for(c, (const void*)k_st_shade<7, 1, 0>, kLdsNodes, GI_SHADE_BLOCK); g.shadow = grid_for(c, (const void*)k_st_shadow<7, 1>, kLdsWideBoxes, GI_SHADOW_BLOCK); g.gather = grid_for(c, (const void*)k_st_gather<false>); g.accum = grid_for(c, (const void*)k_st_accum);
         g.compact = grid_for(c, (const void*)k_st_compact, 0, 256); g.finish = grid_for(c, (const void*)k_st_finish<7, 1, 0>, kLdsNodes, GI_FINISH_BLOCK); g.ad_gen = grid_for(c, (const void*)k_ad_gen); g.ad_accum = grid_for(c, (const void*)k_ad_accum);
     }
     return g;
@@ -1756,6 +1804,10 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
     if (G.lds_refused) return fail(c, GI_E_HIP, "render: the device refused " + std::to_string(G.lds_refused) + " bytes of dynamic LDS per workgroup (the traversal kernels are laid out for gfx950's 160 KB per CU)");
     hipStream_t st = c->stream;
     const bool wide = c->S.wnodes != nullptr;
+    // executed-work counters: compiled for the instances the BASELINE scenes run (triangles only, no medium, no texture, shadow walks put off)
+    const bool counting = c->count_stream;
+    if (counting && !(wide && defers_shadows(c) && !c->S.has_spheres && c->S.n_fog == 0 && c->S.n_tex == 0))
+        return fail(c, GI_E_STATE, "render: the streaming work counters (gi_set_counters 2) cover triangle scenes without spheres, fog or textures, walked over wide records with one to four lights; use mode 1 (reference visits, megakernel) for this scene");
     PathRec* pool = c->d_pool.p;
     StreamCtl* ctl = c->d_ctl.p;
     uint32_t* q_new = c->d_qs[0].p;
@@ -1778,7 +1830,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         if (n_new + n_cont == 0) break;
         uint32_t* qcont_out = q_cont[ping];
         const uint32_t* qcont_in = q_cont[ping ^ 1];
-        if (exhausted && n_new == 0 && n_cont <= c->finish_threshold) {
+        if (exhausted && n_new == 0 && n_cont <= c->finish_threshold && !counting) {   // (a counted frame runs its stragglers through the counting passes)
             const bool sphf = c->S.has_spheres != 0, fogf = c->S.n_fog > 0, texf = c->S.n_tex > 0;
             if (c->d_fin_cnt.n < 16) HIP_TRY(c, c->d_fin_cnt.alloc(16));
             HIP_TRY(c, hipMemsetAsync(c->d_fin_cnt.p, 0, 16 * sizeof(unsigned int), st));
@@ -1811,8 +1863,9 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         const size_t bc_bytes = (size_t)QC_KINDS * GI_MAX_PRODUCER_BLOCKS * GI_CNT_STRIDE * sizeof(unsigned int);
         // trace: hits -> staging 0, finished paths -> staging 1; compacted into the shade queue and the head of the free list
         HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
-        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), wide ? kLdsWideBoxes : kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, bc, c->d_segs.p,
-                           c->d_stage[0].p, c->d_stage[1].p, lbuf, c->refill_min); stage_end(c);
+        StreamCounters* const sc = counting ? c->d_stream_cnt.p : nullptr;
+        stage_begin(c, STG_TRACE); hipLaunchKernelGGL(counting ? (k_st_trace<0, 1, true>) : tex ? (wide ? k_st_trace<7, 1> : k_st_trace<7, 0>) : wide ? (sph ? k_st_trace<GI_FEAT_SPHERES, 1> : k_st_trace<0, 1>) : (sph ? k_st_trace<GI_FEAT_SPHERES, 0> : k_st_trace<0, 0>), dim3(G.trace), dim3(GI_TRACE_BLOCK), wide ? kLdsWideBoxes : kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, gen, q_new, n_prepared, qcont_in, n_cont, bc, c->d_segs.p,
+                           c->d_stage[0].p, c->d_stage[1].p, lbuf, c->refill_min, sc); stage_end(c);
         {
             CompactJob job;
             memset(&job, 0, sizeof job);
@@ -1833,9 +1886,10 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         stage_end(c);
         if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
             stage_begin(c, STG_SHADE);
-            hipLaunchKernelGGL(many ? (tex ? k_st_shadow<7, 1> : fog ? k_st_shadow<3, 1> : sph ? k_st_shadow<GI_FEAT_SPHERES, 1> : k_st_shadow<0, 1>)
-                                    : (tex ? k_st_shadow<7, 0> : fog ? k_st_shadow<3, 0> : sph ? k_st_shadow<GI_FEAT_SPHERES, 0> : k_st_shadow<0, 0>), dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsWideBoxes, st,
-                               c->S, F.seed, pool, shq, ctl, lbuf, c->refill_min);
+            hipLaunchKernelGGL(counting ? (many ? (k_st_shadow<0, 1, true>) : (k_st_shadow<0, 0, true>))
+                               : many ? (tex ? k_st_shadow<7, 1> : fog ? k_st_shadow<3, 1> : sph ? k_st_shadow<GI_FEAT_SPHERES, 1> : k_st_shadow<0, 1>)
+                                      : (tex ? k_st_shadow<7, 0> : fog ? k_st_shadow<3, 0> : sph ? k_st_shadow<GI_FEAT_SPHERES, 0> : k_st_shadow<0, 0>), dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsWideBoxes, st,
+                               c->S, F.seed, pool, shq, ctl, lbuf, c->refill_min, sc);
             stage_end(c);
             launches++;
         }
@@ -1857,6 +1911,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         HIP_TRY(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(StreamCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         const uint32_t n_gather = c->h_ctl->n_gather;
+        if (counting) c->stream_shaded += c->h_ctl->n_shade;
         if (c->S.n_pnode > 0 && n_gather > 0) {
             int bits = 1;
             while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
@@ -1864,7 +1919,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             stage_begin(c, STG_SORT);
             HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
             stage_end(c);
-            stage_begin(c, STG_GATHER); hipLaunchKernelGGL(k_st_gather, dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf); stage_end(c);
+            stage_begin(c, STG_GATHER); hipLaunchKernelGGL(counting ? (k_st_gather<true>) : (k_st_gather<false>), dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf, sc); stage_end(c);
             launches += 2;
         }
         n_cont = c->h_ctl->n_cont;
@@ -1912,6 +1967,11 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     hipStream_t st = c->stream;
     int launches = 0;
     c->ev_used = 0; c->ev_stage.clear();
+    if (c->count_stream) {
+        if (!c->d_stream_cnt.p) HIP_TRY(c, c->d_stream_cnt.alloc(1));
+        HIP_TRY(c, hipMemsetAsync(c->d_stream_cnt.p, 0, sizeof(StreamCounters), st));
+        c->stream_shaded = 0;
+    }
     HIP_TRY(c, hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(k_wf_init, dim3(G.init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
     launches++;
@@ -2011,6 +2071,8 @@ int gi_render_device(gi_ctx* c, const gi_render_params* p, void* d_out, int out_
     if (c->render_mode == 1 || c->count_enabled) return render_megakernel(c, F, d_out, out_is_f64, d_spp);
     // fixed sample count: streaming pool with path regeneration; adaptive sampling: rounds (sample-order decisions) on the same passes;
     // mode 2: the plain per-depth rounds, kept as a second schedule of the same arithmetic
+    if (c->count_stream && !(c->render_mode == 0 && F.min_samples == F.max_samples && F.max_samples > 0))
+        return fail(c, GI_E_STATE, "render: the streaming work counters (gi_set_counters 2) belong to fixed-sample-count frames of the wavefront pipeline");
     if (c->render_mode == 0 && F.min_samples == F.max_samples && F.max_samples > 0) return render_streaming(c, F, d_out, out_is_f64, d_spp, cancel);
     if (c->render_mode == 0) return render_adaptive(c, F, d_out, out_is_f64, d_spp, cancel);
     return render_wavefront(c, F, d_out, out_is_f64, d_spp, cancel);
@@ -2075,7 +2137,26 @@ int gi_last_stage_ms(gi_ctx* c, float* out8)
     return GI_OK;
 }
 
-int gi_set_counters(gi_ctx* c, int enable) { if (!c) return GI_E_INVALID; c->count_enabled = enable != 0; return GI_OK; }
+int gi_set_counters(gi_ctx* c, int enable)
+{
+    if (!c || enable < 0 || enable > 2) return GI_E_INVALID;
+    c->count_enabled = enable == 1;
+    c->count_stream = enable == 2;
+    return GI_OK;
+}
+int gi_get_stream_counters(gi_ctx* c, int64_t* out17)
+{
+    if (!c || !out17) return GI_E_INVALID;
+    if (!c->d_stream_cnt.p) return fail(c, GI_E_STATE, "stream counters: no counted frame was rendered (gi_set_counters(ctx, 2), fixed sample count)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    StreamCounters h;
+    HIP_TRY(c, hipMemcpy(&h, c->d_stream_cnt.p, sizeof h, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; k++) { out17[k] = (int64_t)h.trace[k]; out17[7 + k] = (int64_t)h.shadow[k]; }
+    out17[6] = (int64_t)h.trace_rays; out17[13] = (int64_t)h.shadow_rays;
+    out17[14] = (int64_t)h.gather_queries; out17[15] = (int64_t)h.gather_cand; out17[16] = (int64_t)c->stream_shaded;
+    return GI_OK;
+}
 int gi_get_counters(gi_ctx* c, int64_t* out8)
 {
     if (!c || !out8) return GI_E_INVALID;

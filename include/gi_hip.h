@@ -144,10 +144,18 @@ int gi_last_render_ms(gi_ctx*, float* ms, int32_t* n_launches);
 /* Device time per pipeline stage of the last render, summed over its launches (HIP events around every launch):
  * [0] regenerate, [1] trace, [2] shade, [3] sorts (+ key kernels), [4] gather, [5] finish, [6] accumulate, [7] other.      */
 int gi_last_stage_ms(gi_ctx*, float* out8);
-/* Work counters of the last render (when enabled with gi_set_counters(ctx,1)): node visits in trace, node visits in
- * visible, triangle tests, shaded hits, photon candidates, trace calls, shadow rays, gathers.                              */
-int gi_set_counters(gi_ctx*, int enable);
+/* Work counters of the last render.  gi_set_counters(ctx, 1): the REFERENCE's visits -- the frame is rendered by the megakernel with the
+ * per-node walk and nothing culled, and gi_get_counters gives node visits in trace (BoundingBox::intersect calls of Octree::Node::intersectSorted,
+ * include/octree.cpp:285-313), node visits in visible, triangle tests, shaded hits, photon candidates, trace calls, shadow rays, gathers.
+ * gi_set_counters(ctx, 2): what the streaming kernels EXECUTE -- the frame is rendered by the pipeline that is benchmarked, its walks count per
+ * lane, and gi_get_stream_counters gives out17 = k_st_trace: [0] walks begun (root box tests), [1] wide records visited, [2] child boxes tested
+ * from them, [3] content boxes tested, [4] non-empty leaves met, [5] entity tests, [6] rays handed to the kernel; k_st_shadow: [7..12] the same
+ * six, [13] shadow segments; [14] gather queries, [15] photon candidates they scanned, [16] shaded hits.  With content-box culling off,
+ * [0] + [2] and [5] are the reference's node visits and entity tests of trace() exactly.  Covers fixed-sample-count frames of triangle scenes
+ * without spheres, fog or textures (the BASELINE scenes); other scenes get GI_E_STATE.  0 = off (default).                                  */
+int gi_set_counters(gi_ctx*, int mode);
 int gi_get_counters(gi_ctx*, int64_t* out8);
+int gi_get_stream_counters(gi_ctx*, int64_t* out17);
 
 /* Function-level entry points (parity tests and the C++ API's public methods).  Host pointers.
  * replaces RayTracer::trace (include/raytracer.h:382-478): rays [n][6] origin + unit dir -> hit, entity, res [n][8]        */

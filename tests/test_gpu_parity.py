@@ -433,7 +433,7 @@ def test_baseline_configs_at_their_own_spp_match_oracle(name, w, h, spp, photons
     d = img[rows] - ref[rows]
     rmse = float(np.sqrt((d ** 2).mean()))
     print(f"{name} {w}x{h} {spp} spp: rmse vs oracle on rows {rows.tolist()} = {rmse:.3e}, max |diff| {np.abs(d).max():.3e}, mean radiance {img.mean():.6f}")
-    assert rmse < (1e-6 if name == "teapot" else 1e-8), rmse
+    assert rmse < (1e-5 if name == "teapot" else 1e-8), rmse      # measured (MI355X): cornell 1.2e-15, caustics 1.7e-18, teapot 6.7e-7 (max |diff| 6.1e-5)
     assert np.median(np.abs(d)) < 1e-12
 
 
@@ -445,6 +445,55 @@ def test_textured_glass_scene_at_256_spp_is_inside_the_contract():
     rmse, img, ref = pc.check_render(rt, scene, 96, 54, 256, 5000, tol=1e-4)
     print("cornell_tex 96x54 256 spp rmse", rmse, "pixels off", (np.abs(img - ref).max(axis=2) > 1e-9).mean())
     assert np.median(np.abs(img - ref)) < 1e-12
+
+
+@pytest.mark.parametrize("name,photons", [("cornell", 0), ("caustics", 5000), ("teapot", 3000)])
+def test_streaming_work_counters_against_the_reference_counts(name, photons):
+    """gi_set_counters(ctx, 2): what the streaming kernels execute.  With content-box culling OFF the walk of k_st_trace meets the leaves of
+    Octree::intersectSorted's list in the same order and stops after the same one, so it tests exactly the entities RayTracer::trace tests
+    (include/raytracer.h:446-472): its entity tests equal the oracle's T_trace; the any-hit shadow walk stops at the first blocker like the
+    reference's candidate loop (include/raytracer.h:290-305), in front-to-back instead of DFS order: T_shadow within a few per cent.  Box tests stay at or below the reference's, which walks the whole
+    tree along the ray before it tests anything (include/octree.cpp:188-211,256-313) where the device walks on demand; walks begun equal the
+    reference's trace() / visible() calls; gather queries, candidates and shaded hits are equal too.  With culling ON (the product's default) the frame is the same bit for bit and the counters shrink: that ratio is what
+    bench.py prints next to the reference's work."""
+    scene = pc.load_scene(name)
+    rt = gi.RayTracer(0).setScene(scene)
+    o = pc.oracle_for(scene)
+    ph = np.zeros((0, 9))
+    if photons:
+        ph, _ = rt.tracePhotons(photons)
+    o.set_photons(ph).build_photon_map()
+    w, h, spp = 64, 40, 6
+    ref = o.render(w, h, spp, want_counters=True)
+    oc = ref["counters"]           # v_trace, v_shadow, tri, shaded, pcand, traces, shadows, gathers, tri_shadow
+    plain = rt.run(w, h, min_samples=spp, max_samples=spp)
+    rt.set_counters("stream")
+    try:
+        rt.set_content_culling(False)
+        a = rt.run(w, h, min_samples=spp, max_samples=spp)
+        c0 = rt.stream_counters()
+        assert rt.set_content_culling(True)
+        b = rt.run(w, h, min_samples=spp, max_samples=spp)
+        c1 = rt.stream_counters()
+    finally:
+        rt.set_counters(0)
+        rt.set_content_culling(True)
+    assert np.array_equal(a.view(np.uint64), plain.view(np.uint64)) and np.array_equal(b.view(np.uint64), plain.view(np.uint64))   # counting changes nothing
+    # trace(): one root test per call (a ray that misses the root box -- a camera ray outside the scene -- begins a walk and tests nothing else)
+    assert c0["trace_walks"] == oc[5] and c0["trace_rays"] >= oc[5] and c0["trace_walks"] + c0["trace_child_boxes"] <= oc[0], (c0, oc)
+    assert c0["trace_tris"] == oc[2] - oc[8]
+    # visible(): the reference tests the candidates of the touched leaves in its DFS (child 0..7) order until one blocks, the device meets the leaves
+    # front to back -- the same answer (any blocker), about the same number of tests
+    assert abs(c0["shadow_tris"] - oc[8]) <= 0.05 * oc[8], (c0["shadow_tris"], oc[8])
+    assert c0["shadow_walks"] == oc[6] and c0["shadow_rays"] == oc[6] and c0["shadow_walks"] + c0["shadow_child_boxes"] <= oc[1]
+    assert c0["shaded"] == oc[3] and c0["gather_queries"] == oc[7] and c0["gather_candidates"] == oc[4]
+    assert c0["trace_content_boxes"] == 0 and c1["trace_content_boxes"] > 0
+    # culling on: same rays, same shaded hits and gathers, fewer boxes and entity tests
+    for k in ("trace_rays", "trace_walks", "shadow_rays", "shaded", "gather_queries", "gather_candidates"):
+        assert c1[k] == c0[k], k
+    assert c1["trace_child_boxes"] < c0["trace_child_boxes"] and c1["trace_tris"] <= c0["trace_tris"] and c1["shadow_tris"] <= c0["shadow_tris"]
+    print(name, "executed / reference: boxes %.3f, entity tests %.3f" % ((c1["trace_walks"] + c1["trace_child_boxes"] + c1["shadow_walks"] + c1["shadow_child_boxes"]) / (oc[0] + oc[1]),
+                                                                      (c1["trace_tris"] + c1["shadow_tris"]) / oc[2]))
 
 
 def test_eight_bit_frame_matches_oracle():
