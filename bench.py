@@ -12,9 +12,12 @@ ends with one RCCL gather of the float-RGB stripes to rank 0, inside the timed r
 torch.cuda.synchronize() on both sides of exactly K steps, MAX over ranks.
 
 Extra objects on the JSON line:
-  "roofline"      algorithmic HBM-class bytes of the pipeline / its HIP-event duration against 8 TB/s
-                  ("algorithmic_frac"; those bytes are served from LDS / L2, so this is a work rate, not a bus load), the PMC-measured
-                  HBM traffic of the same frame and what share of the HBM peak it is ("hbm_measured_frac"), per stage and for the dominant kernel;
+  "roofline"      for the dominant kernel (by live HIP-event time) and for every hot kernel: the resource that binds it and the fraction of that
+                  resource's peak it reaches -- VALU issue (vector-ALU busy quad-cycles of the committed SQ counter profile / the live kernel
+                  time against 1024 SIMDs at 2.4 GHz) or HBM (TCC bytes of the committed profile / the live kernel time against 8 TB/s); every
+                  fraction is <= 1 by construction.  Next to it "reference_work": the SURVEY 8(d) bytes of the REFERENCE algorithm per second
+                  (a work rate -- those tables live in LDS / L2, so it is not a bus load and carries no "frac"), and "executed_work": what the
+                  streaming kernels executed (their own counters, one extra untimed frame) against the reference's visits;
   "cpu_baseline"  at N=1: the CPU oracle, OpenMP on the box's host cores, on a bounded sample of the same workload;
   "other_configs" at N=1: BASELINE configs 2 (cornell 512x512x64 spp, closed box) and 4 (cornell + glass teapot 1080p x 256 spp, 200 k photons).
 """
@@ -47,6 +50,7 @@ def parse_args():
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU-baseline sample (-1: sized for ~12 s, 0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the other_configs lines (BASELINE configs 2 and 4)")
+    ap.add_argument("--no-executed", action="store_true", help="skip the extra counted frame (executed_work); the profiler passes use this so that every launch they see belongs to a timed frame")
     ap.add_argument("--pool", type=int, default=0, help="path slots of the wavefront pool (0: library default)")
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "rounds", "megakernel"])
     ap.add_argument("--write-mix", action="store_true", help="record the oracle-counted per-sample mix of this workload in profiles/workload_mix.json")
@@ -91,61 +95,106 @@ def stored_mix(key):
         return None
 
 
-def measured_traffic(scene, w, h, spp, photons, world, mode):
-    """HBM bytes of one frame from the TCC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes), as committed under
-    profiles/ for exactly this workload; bench.py cannot sit under the profiler itself.  FETCH_SIZE is doubled as
-    MI355X_MICROARCH.md (HBM section) prescribes for gfx950."""
-    import glob
+N_SIMD = 256 * 4           # MI355X: 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9           # peak engine clock (MI355X_MICROARCH.md); the chip may hold less under load, which only lowers a busy fraction computed with it
+VALU_PEAK_GQC = N_SIMD * CLOCK_HZ / 4 / 1e9   # VALU-busy quad-cycles per second the chip can deliver: one 64-wide VALU instruction = one quad-cycle of a SIMD
+HBM_ACHIEVABLE_GBS = 6290.0                   # measured float4 copy (MI355X_MICROARCH.md, HBM section)
+KERNEL_OF = {"trace": "k_st_trace", "shade": "k_st_shade", "shadow": "k_st_shadow", "gather": "k_st_gather", "finish": "k_st_finish", "other": "k_st_compact", "accum": "k_st_accum"}
+
+
+def _natural(p):
     import re
-    best = None
-    natural = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]   # r01_v10 after r01_v9, r02 after r01
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), key=natural):
+    return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]   # r01_v10 after r01_v9, r03 after r02
+
+
+def committed_profile(suffix, scene, w, h, spp, photons, world, mode):
+    """The latest profiles/*<suffix> recorded for exactly this workload (rocprofv3 --pmc passes of `bench.py`, folded by tools/fold_profile.py);
+    bench.py cannot sit under the profiler itself.  Returns (relative path, dict) or (None, None)."""
+    import glob
+    best = (None, None)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)), key=_natural):
         try:
             with open(path) as f:
                 d = json.load(f)
         except (OSError, ValueError):
             continue
-        if d.get("workload_key") == {"scene": scene, "frame": [w, h], "spp": spp, "photons": photons, "n_gpus": world, "mode": mode}:
-            best = (path, d)
-    if best is None:
-        return None
-    path, d = best
-    per_kernel = {k: 2.0 * v["FETCH_SIZE_KB"] * 1024 + v["WRITE_SIZE_KB"] * 1024 for k, v in d.get("per_kernel", {}).items()}
-    return {"traffic": 2.0 * d["frame_fetch_bytes_uncorrected"] + d["frame_write_bytes"], "traffic_unit": "bytes per frame (one pass of the pipeline)",
-            "traffic_source": os.path.relpath(path, ROOT) + ": 2 x FETCH_SIZE + WRITE_SIZE", "_per_kernel": per_kernel}
+        wk = d.get("workload_key") or dict(d.get("workload", {}), n_gpus=1, mode="wavefront")
+        if wk == {"scene": scene, "frame": [w, h], "spp": spp, "photons": photons, "n_gpus": world, "mode": mode}:
+            best = (os.path.relpath(path, ROOT), d)
+    return best
 
 
-def roofline_of(scene_name, w, h, spp, photons, world, mode, local_samples, stages, kernel_ms_avg, mix):
-    """The roofline object for one workload; mix = per-sample counts of the reference algorithm (oracle), or None when unknown."""
-    pipeline_ms = sum(stages.values()) if stages and sum(stages.values()) > 0 else kernel_ms_avg   # megakernel mode: one launch
-    r = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-         "kernel": "streaming wavefront pipeline of one frame: k_st_trace (+ path start), k_st_shade, k_st_shadow, k_st_compact (+ gather keys), sorts, k_st_gather, k_st_finish, k_st_accum"
-                   if mode == "wavefront" else mode,
-         "kernel_ms": pipeline_ms, "frame_ms_event_to_event": kernel_ms_avg, "stage_ms": stages}
+def _sum_family(per_kernel, family, field):
+    """Sum a counter over the instances of one kernel family ('k_st_trace' matches 'k_st_trace<0, 1, false>')."""
+    tot, hit = 0.0, False
+    for name, d in per_kernel.items():
+        if name.split("<")[0] == family and field(d) is not None:
+            tot += field(d)
+            hit = True
+    return tot if hit else None
+
+
+def roofline_of(scene_name, w, h, spp, photons, world, mode, local_samples, kernels, kernel_ms_avg, mix, executed):
+    """kernels: live HIP-event ms per kernel family of one frame; mix: per-sample visits of the reference algorithm (oracle) or None;
+    executed: per-sample counters of the streaming kernels or None."""
+    pipeline_ms = sum(kernels.values()) if kernels and sum(kernels.values()) > 0 else kernel_ms_avg   # megakernel mode: one launch
+    sq_path, sq = committed_profile("_sq_pmc.json", scene_name, w, h, spp, photons, world, mode)
+    hb_path, hb = committed_profile("_hbm_traffic.json", scene_name, w, h, spp, photons, world, mode)
+    per = {}
+    for fam_key, fam in KERNEL_OF.items():
+        ms = kernels.get(fam_key, 0.0)
+        if ms <= 0:
+            continue
+        e = {"ms_per_frame": ms}
+        if sq:
+            act = _sum_family(sq["per_kernel"], fam, lambda d: d.get("SQ_ACTIVE_INST_VALU", {}).get("sum"))
+            thr = _sum_family(sq["per_kernel"], fam, lambda d: d.get("SQ_THREAD_CYCLES_VALU", {}).get("sum"))
+            wav = _sum_family(sq["per_kernel"], fam, lambda d: d.get("SQ_WAVE_CYCLES", {}).get("sum"))
+            if act:
+                gqc = act / (ms * 1e-3) / 1e9                      # VALU-busy quad-cycles per second, live time
+                e["valu"] = {"achieved": gqc, "peak": VALU_PEAK_GQC, "unit": "G VALU-busy quad-cycles/s", "frac": gqc / VALU_PEAK_GQC,
+                             "lanes_per_valu": (thr / act) if thr else None, "valu_active_share_of_wave_cycles": (act / wav) if wav else None}
+        if hb:
+            byt = _sum_family(hb.get("per_kernel", {}), fam, lambda d: 2.0 * d["FETCH_SIZE_KB"] * 1024 + d["WRITE_SIZE_KB"] * 1024)
+            if byt:
+                gbs = byt / (ms * 1e-3) / 1e9
+                e["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_achievable": gbs / HBM_ACHIEVABLE_GBS,
+                            "traffic": byt, "traffic_per_sample": byt / local_samples}
+        # the binding resource: the one closest to its peak
+        cands = [(k, e[k]["frac"]) for k in ("valu", "hbm") if k in e]
+        if cands:
+            b = max(cands, key=lambda kv: kv[1])
+            e["bound"], e["frac"] = ("valu_issue" if b[0] == "valu" else "hbm"), b[1]
+        per[fam] = e
+    dom_key = max(kernels, key=lambda k: kernels.get(k, 0.0)) if kernels else None
+    dom = per.get(KERNEL_OF.get(dom_key, ""), {}) if dom_key else {}
+    res = dom.get("valu" if dom.get("bound") == "valu_issue" else "hbm", {})
+    r = {"kernel": KERNEL_OF.get(dom_key, mode), "bound": dom.get("bound"), "achieved": res.get("achieved"), "peak": res.get("peak"), "unit": res.get("unit"),
+         "frac": dom.get("frac"), "traffic": dom.get("hbm", {}).get("traffic"), "traffic_unit": "HBM bytes of this kernel per frame (all its launches): 2 x FETCH_SIZE + WRITE_SIZE",
+         "lanes_per_valu": dom.get("valu", {}).get("lanes_per_valu"), "hbm_frac": dom.get("hbm", {}).get("frac"),
+         "kernel_ms": dom.get("ms_per_frame"), "pipeline_ms": pipeline_ms, "frame_ms_event_to_event": kernel_ms_avg, "stage_ms": kernels,
+         "per_kernel": per,
+         "evidence": {"sq_counters": sq_path, "hbm_traffic": hb_path,
+                      "how": "instruction / byte counts per frame from the committed rocprofv3 --pmc passes of this command (a property of binary + workload), "
+                             "divided by the kernels' live HIP-event times of this run; tools/check_profile_agreement.py re-derives every fraction"}}
+    if hb:
+        tot = 2.0 * hb["frame_fetch_bytes_uncorrected"] + hb["frame_write_bytes"]
+        r["pipeline_hbm"] = {"traffic": tot, "traffic_per_sample": tot / local_samples, "achieved": tot / (pipeline_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": tot / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if mix is not None:
         b = algorithmic_bytes_per_sample(mix, spp)
-        a = b * local_samples / (pipeline_ms * 1e-3) / 1e9
-        r.update({"achieved": a, "frac": a / HBM_PEAK_GBS, "algorithmic_frac": a / HBM_PEAK_GBS, "algorithmic_bytes_per_sample": b, "per_sample_mix": mix,
-                  "note": "achieved / frac follow SURVEY 8(d): bytes the reference algorithm touches per sample / pipeline time.  The scene and photon "
-                          "tables are LDS / L2 resident, so these bytes do not cross the HBM bus and the fraction can exceed 1 (a work rate, not a bus "
-                          "load; content-box culling also skips node visits the reference makes): hbm_measured_frac (PMC) is the bus load; the kernels "
-                          "are latency / issue bound (profiles/*_sq_pmc.json)."})
-        if stages and sum(stages.values()) > 0:
-            stage_bytes = {"trace": 32 * mix["V_trace"] + 36 * mix["T_trace"], "shade": 32 * mix["V_shadow"] + 36 * mix["T_shadow"] + 96 * mix["H"], "gather": 36 * mix["P"]}
-            r["stage_algorithmic_frac"] = {k: (v * local_samples / (stages[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if stages.get(k, 0) > 0 else None) for k, v in stage_bytes.items()}
-            dom = max(stage_bytes, key=lambda k: stages.get(k, 0.0))
-            if stages.get(dom, 0) > 0:
-                a = stage_bytes[dom] * local_samples / (stages[dom] * 1e-3) / 1e9
-                r["dominant"] = {"kernel": "k_st_" + dom, "ms_per_frame": stages[dom], "algorithmic_bytes_per_sample": stage_bytes[dom], "achieved": a, "frac": a / HBM_PEAK_GBS}
-    tr = measured_traffic(scene_name, w, h, spp, photons, world, mode)
-    if tr is not None:
-        per_kernel = tr.pop("_per_kernel")
-        r.update(tr)
-        r["hbm_measured_frac"] = tr["traffic"] / (pipeline_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        dom = r.get("dominant")
-        if dom and dom["kernel"] in per_kernel:      # the dominant kernel's own HBM bytes per frame (all its launches)
-            dom["traffic"] = per_kernel[dom["kernel"]]
-            dom["hbm_measured_frac"] = dom["traffic"] / (dom["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["reference_work"] = {"bytes_per_sample": b, "per_sample_mix": mix, "rate_GBps": b * local_samples / (pipeline_ms * 1e-3) / 1e9,
+                               "note": "SURVEY 8(d): bytes the REFERENCE algorithm touches per sample (32 V + 36 T + 96 H + 36 P + 12/spp, counted by the oracle) x samples / pipeline time.  "
+                                       "A work rate: the scene and photon tables are LDS / L2 resident and part of the reference's visits is never made (executed_work), so it is "
+                                       "not bounded by the HBM peak and is not a roofline fraction."}
+    if executed is not None:
+        ex = dict(executed)
+        ex["boxes"] = ex["trace_walks"] + ex["trace_child_boxes"] + ex["shadow_walks"] + ex["shadow_child_boxes"]
+        ex["entity_tests"] = ex["trace_tris"] + ex["shadow_tris"]
+        r["executed_work"] = {"per_sample": ex, "source": "gi_set_counters(ctx, 2): per-lane counters of k_st_trace / k_st_shadow / k_st_gather over one extra, untimed frame"}
+        if mix is not None:
+            r["executed_work"]["vs_reference"] = {"boxes": ex["boxes"] / mix["V"] if mix["V"] else None, "entity_tests": ex["entity_tests"] / mix["T"] if mix["T"] else None,
+                                                  "photon_candidates": ex["gather_candidates"] / mix["P"] if mix["P"] else None, "shaded_hits": ex["shaded"] / mix["H"] if mix["H"] else None}
     return r
 
 
@@ -213,7 +262,7 @@ def main():
             fg.gather()                                    # N > 1: one RCCL gather of the stripes to rank 0 (inside the timed region)
             if record:
                 kernel_ms.append(rt.last_render_ms()[0])   # HIP events on the launch stream (synchronises on the second event)
-                stage_ms.append(rt.last_stage_ms())        # HIP events around every launch, summed per pipeline stage
+                stage_ms.append(rt.last_kernel_ms())       # HIP events around every launch, summed per kernel family
 
         for _ in range(warmup):
             step(False)
@@ -230,7 +279,18 @@ def main():
             elapsed, kernel_ms_avg = float(tt[0].item()), float(tt[1].item())
         stages = {k: float(np.mean([s[k] for s in stage_ms])) for k in stage_ms[0]} if stage_ms else {}
         img = fg.frame.cpu().numpy() if rank == 0 else None
-        return {"scene": scene, "rt": rt, "elapsed": elapsed, "kernel_ms": kernel_ms_avg, "stages": stages, "img": img, "rows": rows, "n_photons": n_photons, "photons_asked": photons, "setup_s": setup_s}
+        executed = None
+        if rank == 0 and world == 1 and args.mode == "wavefront" and not args.no_executed:      # what the kernels executed: one more frame, untimed, with their counters on
+            try:
+                rt.set_counters("stream")
+                rt.run_device(p, fg.local.data_ptr(), f64=False)
+                torch.cuda.synchronize()
+                executed = {k: v / float(rows * w * spp) for k, v in rt.stream_counters().items()}
+            except gi.GiError:
+                executed = None                                       # a scene the counting instances do not cover
+            finally:
+                rt.set_counters(0)
+        return {"executed": executed, "scene": scene, "rt": rt, "elapsed": elapsed, "kernel_ms": kernel_ms_avg, "stages": stages, "img": img, "rows": rows, "n_photons": n_photons, "photons_asked": photons, "setup_s": setup_s}
 
     def cpu_leg(res, scene_name, w, h, spp, budget_s, cores):
         """The oracle (the checker) timed on the host cores on full-width rows spread over the frame; returns (cpu_baseline, mix, rmse)."""
@@ -255,7 +315,7 @@ def main():
         lin, cnt = o.render_rows(w, h, rows_sel, spp, rt.seed, cores)
         cpu_s = time.perf_counter() - tc
         n_s = len(rows_sel) * w * spp
-        cpu = {"value": n_s / cpu_s / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+        cpu = {"value": n_s / cpu_s / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "sampled": True,
                "sample": f"{len(rows_sel)} full-width rows spread evenly over the {w}x{h} frame at {spp} spp = {n_s} samples in {cpu_s:.1f} s (OpenMP oracle, rows dealt dynamically to {cores} threads)"}
         rmse = float(np.sqrt(((res["img"][rows_sel].astype(np.float64) - lin[rows_sel]) ** 2).mean()))
         return cpu, mix_from_counters(cnt, n_s), rmse
@@ -291,9 +351,8 @@ def main():
                 allmix[key] = mix
                 with open(MIX_FILE, "w") as f:
                     json.dump(allmix, f, indent=1, sort_keys=True)
-        out["roofline"] = roofline_of(args.scene, w, h, spp, args.photons, world, args.mode, res["rows"] * w * spp, res["stages"], res["kernel_ms"], mix)
-        if mix is None:
-            out["roofline"]["note"] = "no oracle-counted per-sample mix for this workload (run the N=1 CPU leg with --write-mix): algorithmic bytes unknown, achieved / frac omitted"
+        out["roofline"] = roofline_of(args.scene, w, h, spp, args.photons, world, args.mode, res["rows"] * w * spp, res["stages"], res["kernel_ms"], mix, res["executed"])
+        out["config"]["library"] = os.path.relpath(gi.LIB_PATH, ROOT)
         if cpu is not None:
             out["cpu_baseline"] = cpu
     del res
@@ -311,7 +370,7 @@ def main():
             if not args.no_cpu and args.cpu_rows != 0:
                 c, mix, rmse = cpu_leg(r, name, ow, oh, ospp, 4.0, cores)
                 o["cpu_baseline"], o["rmse_vs_oracle_on_cpu_rows"] = c, rmse
-            o["roofline"] = roofline_of(name, ow, oh, ospp, oph, 1, args.mode, ow * oh * ospp, r["stages"], r["kernel_ms"], mix)
+            o["roofline"] = roofline_of(name, ow, oh, ospp, oph, 1, args.mode, ow * oh * ospp, r["stages"], r["kernel_ms"], mix, r["executed"])
             others.append(o)
             del r
         out["other_configs"] = others

@@ -61,7 +61,7 @@ _LIB = None
 # every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
-    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_set_counters", "gi_get_counters", "gi_get_stream_counters", "gi_trace", "gi_visible",
+    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_last_kernel_ms", "gi_set_counters", "gi_get_counters", "gi_get_stream_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
     "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
@@ -96,6 +96,7 @@ def lib():
     L.gi_set_pool_slots.argtypes = [vp, C.c_int64]
     L.gi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), _ip]
     L.gi_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.gi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.gi_set_counters.argtypes = [vp, C.c_int]
     L.gi_get_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     L.gi_get_stream_counters.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -542,6 +543,14 @@ class RayTracer:
         out = (C.c_float * 8)()
         self._check(self.L.gi_last_stage_ms(self.h, out), "last_stage_ms")
         return dict(zip(self.STAGES, [float(v) for v in out]))
+
+    KERNELS = ("regen", "trace", "shade", "sort", "gather", "finish", "accum", "other", "shadow", "reserved")
+
+    def last_kernel_ms(self):
+        """gi_last_kernel_ms: device time of the last frame per kernel family ('shade' = k_st_shade alone, 'shadow' = k_st_shadow)."""
+        out = (C.c_float * 10)()
+        self._check(self.L.gi_last_kernel_ms(self.h, out), "last_kernel_ms")
+        return {k: float(v) for k, v in zip(self.KERNELS, out) if k != "reserved"}
 
     def set_counters(self, mode):
         """0 / False: off; 1 / True: the reference's visits (megakernel, per-node walk); 2 or "stream": what the streaming kernels execute."""

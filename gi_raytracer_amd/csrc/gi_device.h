@@ -131,6 +131,9 @@ struct Scene {
     const Mat* mats;
     const LightD* lights;
     const PNode* pnodes;
+    const int32_t* pleaf_rank;   // [n_pnode] rank of a leaf among the leaves with candidate photons (the gather queries' sort key), -1 for every other node
+    const int32_t* prank_leaf;   // [n_pleaf] its inverse
+    int32_t n_pleaf;             // leaves with candidates
     const PRange* pranges;
     const double* ph_pos;     // [n_photon][3] leaf order
     const double* ph_dircol;  // [n_photon][6] leaf order

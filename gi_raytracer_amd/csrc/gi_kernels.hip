@@ -890,6 +890,37 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
 // workgroup recomputes the prefix sums of the (at most 2048) per-workgroup counts in LDS; workgroup 0 leaves the totals in StreamCtl.
 // The queue of gather queries is not copied but turned into the input of its sort: (key = photon-map leaf that contains the query's
 // position, value = slot) -- PhotonMap::Node::getBounds' descent (gather_find_leaf) runs here, on positions read in queue order.
+// Gather queries are sorted by the leaf of the photon octree they fall in; only leaves that have candidate photons matter (a query anywhere else
+// adds nothing), so the sort key is the leaf's rank among those -- 15 bits for the 200 000-photon map of the benchmark (27 k such leaves of 72 k
+// nodes: two 8-bit digit passes of the radix sort instead of three) -- and every other query gets the one key past them.  One workgroup, at upload.
+__global__ __launch_bounds__(1024) void k_pleaf_rank(const PNode* nodes, int32_t n, int32_t* rank, int32_t* inv, int32_t* n_out)
+{
+    __shared__ int32_t part[1024];
+    __shared__ int32_t base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int32_t i0 = 0; i0 < n; i0 += 1024) {
+        const int32_t i = i0 + (int32_t)threadIdx.x;
+        const int32_t f = (i < n && nodes[i].first_child < 0 && nodes[i].u.lf.nb_photons > 0) ? 1 : 0;
+        part[threadIdx.x] = f;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {   // inclusive prefix sums
+            const int32_t v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (i < n) {
+            const int32_t r = base + part[threadIdx.x] - 1;
+            rank[i] = f ? r : -1;
+            if (f) inv[r] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) base += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = base;
+}
 struct CompactStream { const uint32_t* src; uint32_t* dst; int width; };
 struct CompactJob {
     CompactStream st[5];    // streams of queue A (e.g. slot + key), then queue B, queue C: n_streams[q] streams each
@@ -934,7 +965,8 @@ __global__ __launch_bounds__(256) void k_st_compact(Scene S, CompactJob job, con
                 const double* pos = reinterpret_cast<const double*>(job.st[stream0 + 1].src) + from * 3;
                 const int32_t leaf = gather_find_leaf(S, v3(pos[0], pos[1], pos[2]));
                 sl.dst[to] = sl.src[from];
-                job.st[stream0 + 1].dst[to] = leaf < 0 ? (uint32_t)S.n_pnode : (uint32_t)leaf;
+                const int32_t rank = leaf < 0 ? -1 : S.pleaf_rank[leaf];
+                job.st[stream0 + 1].dst[to] = rank < 0 ? (uint32_t)S.n_pleaf : (uint32_t)rank;   // the key past the last leaf: nothing to gather
                 continue;
             }
             for (int k = 0; k < job.n_streams[q]; k++) {
@@ -1014,9 +1046,10 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
         if (u >= total) break;
         const uint32_t i = ((u / cs) * gridDim.x + blockIdx.x) * cs + u % cs + lane;
         const bool valid = i < n_in;
-        const uint32_t leaf = valid ? keys[i] : 0xffffffffu;
+        const uint32_t rank = valid ? keys[i] : 0xffffffffu;                       // rank of the query's leaf among the leaves with candidates
+        const bool has_leaf = valid && rank < (uint32_t)S.n_pleaf;
+        const uint32_t leaf = has_leaf ? (uint32_t)S.prank_leaf[rank] : 0xffffffffu;
         const uint32_t leaf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf);
-        const bool has_leaf = valid && leaf < (uint32_t)S.n_pnode;
         const bool uniform = __ballot(valid && leaf != leaf0) == 0ull && leaf0 < (uint32_t)S.n_pnode;
         if constexpr (COUNT) { if (valid) n_q++; }
         if (!uniform) {
@@ -1386,6 +1419,7 @@ struct DevBuf {
 
 }  // namespace
 
+#define STG_COUNT_MAX 10
 struct StreamGrids { int lds_refused = 0; int init = 0, trace = 0, shade = 0, shadow = 0, gather = 0, accum = 0, finish = 0, ad_gen = 0, ad_accum = 0, compact = 0; };
 
 struct gi_ctx {
@@ -1422,6 +1456,7 @@ struct gi_ctx {
     DevBuf<double> d_fog_grid;
     DevBuf<PNode> d_pnodes;
     DevBuf<PRange> d_pranges;
+    DevBuf<int32_t> d_pleaf_rank, d_prank_leaf, d_n_pleaf;
     DevBuf<double> d_ph_pos, d_ph_dircol;
     DevBuf<HaltonDim> d_hdims;
     DevBuf<uint16_t> d_htable;
@@ -1453,7 +1488,7 @@ struct gi_ctx {
     std::vector<int> ev_stage;        // stage id of event pair k (events 2k, 2k+1)
     size_t ev_used = 0;
     bool stage_timing = true;
-    float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float stage_ms[STG_COUNT_MAX] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
     size_t pool_slots_max = (size_t)1 << 30;    // upper bound on paths in flight; the actual pool is also bounded by free HBM (render_streaming)
     uint32_t finish_threshold = 1u << 17;
@@ -1487,6 +1522,23 @@ int fail(gi_ctx* c, int code, const std::string& msg)
     } while (0)
 
 }  // namespace
+
+// the sort key of the gather queries (k_pleaf_rank), for the photon tables c->S points at
+static int install_pleaf_rank(gi_ctx* c)
+{
+    Scene& S = c->S;
+    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0;
+    if (S.n_pnode <= 0) return GI_OK;
+    if (c->d_pleaf_rank.n < (size_t)S.n_pnode) { HIP_TRY(c, c->d_pleaf_rank.alloc((size_t)S.n_pnode)); HIP_TRY(c, c->d_prank_leaf.alloc((size_t)S.n_pnode)); }
+    if (!c->d_n_pleaf.p) HIP_TRY(c, c->d_n_pleaf.alloc(1));
+    hipLaunchKernelGGL(k_pleaf_rank, dim3(1), dim3(1024), 0, c->stream, S.pnodes, S.n_pnode, c->d_pleaf_rank.p, c->d_prank_leaf.p, c->d_n_pleaf.p);
+    HIP_TRY(c, hipGetLastError());
+    int32_t n = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_pleaf.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    S.pleaf_rank = c->d_pleaf_rank.p; S.prank_leaf = c->d_prank_leaf.p; S.n_pleaf = n;
+    return GI_OK;
+}
 
 #include "gi_photon_build.inc"
 
@@ -1606,7 +1658,7 @@ int gi_clear_photons(gi_ctx* c)
 {
     if (!c) return GI_E_INVALID;
     Scene& S = c->S;
-    S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0;
+    S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0; S.n_pleaf = 0;
     return GI_OK;
 }
 
@@ -1620,7 +1672,7 @@ int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
     HIP_TRY(c, hipSetDevice(c->device));
     Scene& S = c->S;
     if (H.n_node == 0) {
-        S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0;
+        S.pnodes = nullptr; S.ph_pos = nullptr; S.ph_dircol = nullptr; S.n_pnode = 0; S.n_photon = 0; S.n_pleaf = 0;
         return GI_OK;
     }
     HIP_TRY(c, c->d_pnodes.upload(H.nodes));
@@ -1632,7 +1684,7 @@ int gi_upload_photons(gi_ctx* c, const gi_photon_map_desc* d)
     S.n_pnode = H.n_node; S.n_photon = H.n_photon;
     c->pn_planes_ok = H.planes_ok;
     S.pn_planes = (c->wide_enabled && c->pn_planes_ok) ? 1 : 0;
-    return GI_OK;
+    return install_pleaf_rank(c);
 }
 
 int gi_local_rows(const gi_render_params* p) { return local_rows(p); }
@@ -1726,7 +1778,7 @@ static int render_wavefront(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     return GI_OK;
 }
 
-enum { STG_REGEN = 0, STG_TRACE, STG_SHADE, STG_SORT, STG_GATHER, STG_FINISH, STG_ACCUM, STG_OTHER };
+enum { STG_REGEN = 0, STG_TRACE, STG_SHADE, STG_SORT, STG_GATHER, STG_FINISH, STG_ACCUM, STG_OTHER, STG_SHADOW, STG_COUNT };
 static void stage_begin(gi_ctx* c, int stage)
 {
     if (!c->stage_timing) return;
@@ -1885,7 +1937,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
                            c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf, shq);
         stage_end(c);
         if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
-            stage_begin(c, STG_SHADE);
+            stage_begin(c, STG_SHADOW);
             hipLaunchKernelGGL(counting ? (many ? (k_st_shadow<0, 1, true>) : (k_st_shadow<0, 0, true>))
                                : many ? (tex ? k_st_shadow<7, 1> : fog ? k_st_shadow<3, 1> : sph ? k_st_shadow<GI_FEAT_SPHERES, 1> : k_st_shadow<0, 1>)
                                       : (tex ? k_st_shadow<7, 0> : fog ? k_st_shadow<3, 0> : sph ? k_st_shadow<GI_FEAT_SPHERES, 0> : k_st_shadow<0, 0>), dim3(G.shadow), dim3(GI_SHADOW_BLOCK), kLdsWideBoxes, st,
@@ -1914,7 +1966,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         if (counting) c->stream_shaded += c->h_ctl->n_shade;
         if (c->S.n_pnode > 0 && n_gather > 0) {
             int bits = 1;
-            while ((1u << bits) <= (uint32_t)c->S.n_pnode) bits++;
+            while ((1u << bits) <= (uint32_t)c->S.n_pleaf) bits++;   // keys 0 .. n_pleaf
             size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
             HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
@@ -1934,7 +1986,15 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         }
         qf = qfree_out;
         ping ^= 1;
-        if (getenv("GI_DEBUG_WF")) fprintf(stderr, "[st] new %u cont %u free %u gather %u\n", n_new, n_cont, n_free, n_gather);
+        if (getenv("GI_DEBUG_WF")) {
+            fprintf(stderr, "[st] new %u cont %u free %u gather %u\n", n_new, n_cont, n_free, n_gather);
+            if (counting) {   // what this pass executed (tuning aid): cumulative counters, printed per pass
+                StreamCounters h;
+                if (hipMemcpy(&h, c->d_stream_cnt.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+                    fprintf(stderr, "[cnt] trace rays %llu walks %llu records %llu boxes %llu cboxes %llu leaves %llu tris %llu | shadow rays %llu records %llu boxes %llu cboxes %llu leaves %llu tris %llu | gather q %llu cand %llu\n",
+                            h.trace_rays, h.trace[0], h.trace[1], h.trace[2], h.trace[3], h.trace[4], h.trace[5], h.shadow_rays, h.shadow[1], h.shadow[2], h.shadow[3], h.shadow[4], h.shadow[5], h.gather_queries, h.gather_cand);
+            }
+        }
     }
     return GI_OK;
 }
@@ -2117,7 +2177,7 @@ int gi_last_render_ms(gi_ctx* c, float* ms, int32_t* n_launches)
         HIP_TRY(c, hipEventSynchronize(c->ev1));
         HIP_TRY(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
     }
-    for (int k = 0; k < 8; k++) c->stage_ms[k] = 0;
+    for (int k = 0; k < STG_COUNT_MAX; k++) c->stage_ms[k] = 0;
     for (size_t k = 0; k + 1 < c->ev_used + 1 && k / 2 < c->ev_stage.size() && k + 1 < c->ev_pool.size() && k < c->ev_used; k += 2) {
         float t = 0;
         if (hipEventElapsedTime(&t, c->ev_pool[k], c->ev_pool[k + 1]) == hipSuccess) c->stage_ms[c->ev_stage[k / 2]] += t;
@@ -2134,6 +2194,16 @@ int gi_last_stage_ms(gi_ctx* c, float* out8)
     int rc = gi_last_render_ms(c, nullptr, nullptr);
     if (rc) return rc;
     for (int k = 0; k < 8; k++) out8[k] = c->stage_ms[k];
+    out8[STG_SHADE] += c->stage_ms[STG_SHADOW];   // the shade stage of the 8-entry form includes the shadow walks it put off
+    return GI_OK;
+}
+
+int gi_last_kernel_ms(gi_ctx* c, float* out10)
+{
+    if (!c || !out10) return GI_E_INVALID;
+    int rc = gi_last_render_ms(c, nullptr, nullptr);
+    if (rc) return rc;
+    for (int k = 0; k < STG_COUNT_MAX; k++) out10[k] = c->stage_ms[k];
     return GI_OK;
 }
 

@@ -144,6 +144,9 @@ int gi_last_render_ms(gi_ctx*, float* ms, int32_t* n_launches);
 /* Device time per pipeline stage of the last render, summed over its launches (HIP events around every launch):
  * [0] regenerate, [1] trace, [2] shade, [3] sorts (+ key kernels), [4] gather, [5] finish, [6] accumulate, [7] other.      */
 int gi_last_stage_ms(gi_ctx*, float* out8);
+/* The same per kernel family, out10: [0..7] as above except [2] = k_st_shade alone, [8] = k_st_shadow (the shadow walks the shade stage put off),
+ * [9] reserved (0).                                                                                                         */
+int gi_last_kernel_ms(gi_ctx*, float* out10);
 /* Work counters of the last render.  gi_set_counters(ctx, 1): the REFERENCE's visits -- the frame is rendered by the megakernel with the
  * per-node walk and nothing culled, and gi_get_counters gives node visits in trace (BoundingBox::intersect calls of Octree::Node::intersectSorted,
  * include/octree.cpp:285-313), node visits in visible, triangle tests, shaded hits, photon candidates, trace calls, shadow rays, gathers.

@@ -486,7 +486,11 @@ def test_streaming_work_counters_against_the_reference_counts(name, photons):
     # front to back -- the same answer (any blocker), about the same number of tests
     assert abs(c0["shadow_tris"] - oc[8]) <= 0.05 * oc[8], (c0["shadow_tris"], oc[8])
     assert c0["shadow_walks"] == oc[6] and c0["shadow_rays"] == oc[6] and c0["shadow_walks"] + c0["shadow_child_boxes"] <= oc[1]
-    assert c0["shaded"] == oc[3] and c0["gather_queries"] == oc[7] and c0["gather_candidates"] == oc[4]
+    assert c0["shaded"] == oc[3]
+    if photons:      # (without a map the reference still calls samplePhotons, which returns at once; the pipeline has no gather stage then)
+        assert c0["gather_queries"] == oc[7] and c0["gather_candidates"] == oc[4]
+    else:
+        assert c0["gather_queries"] == 0 and oc[4] == 0
     assert c0["trace_content_boxes"] == 0 and c1["trace_content_boxes"] > 0
     # culling on: same rays, same shaded hits and gathers, fewer boxes and entity tests
     for k in ("trace_rays", "trace_walks", "shadow_rays", "shaded", "gather_queries", "gather_candidates"):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold one tools/profile_r02.sh output directory (gpurun_out/prof_TAG) into the committed summaries under profiles/:
+"""Fold one tools/profile_r03.sh output directory (gpurun_out/prof_TAG) into the committed summaries under profiles/:
 
   <prefix>_kernel_stats.csv          rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
   <prefix>_bench.json                the bench line of the same command without the profiler
@@ -49,7 +49,7 @@ for name in ("sq_a", "sq_b", "sq_c", "ta", "tcp"):
 for k, d in per.items():
     if "SQ_THREAD_CYCLES_VALU" in d and "SQ_ACTIVE_INST_VALU" in d and d["SQ_ACTIVE_INST_VALU"]["sum"] > 0:
         d["lanes_per_valu"] = d["SQ_THREAD_CYCLES_VALU"]["sum"] / d["SQ_ACTIVE_INST_VALU"]["sum"]
-json.dump({"command": "tools/profile_r02.sh: rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-others (one pass per set)",
+json.dump({"command": "tools/profile_r03.sh: rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-others (one pass per set)",
            "workload": {"scene": wl[0], "frame": [int(wl[1]), int(wl[2])], "spp": int(wl[3]), "photons": int(wl[4])},
            "sets": sets, "per_kernel": per,
            "note": "sums over all launches of one frame; SQ_* cycle counters are in quad-cycles (MI355X_MICROARCH.md); per_wave_cycle = counter / SQ_WAVE_CYCLES of the same pass; "

@@ -2,14 +2,14 @@
 # Profiles of one benchmark frame on the GPU box: rocprofv3 kernel statistics and PMC passes (counters in their own runs, --kernel-trace only),
 # folded on the spot into the summaries that are committed under profiles/ (tools/fold_profile.py); the raw per-dispatch CSVs are dropped
 # (gpurun copies back at most 64 MiB).
-# usage: tools/profile_r02.sh TAG [SCENE W H SPP PHOTONS]   -> gpurun_out/prof_TAG/summary_*     (default: BASELINE config 3)
+# usage: tools/profile_r03.sh TAG [SCENE W H SPP PHOTONS]   -> gpurun_out/prof_TAG/summary_*     (default: BASELINE config 3)
 set -u
 TAG=$1; shift
 SCENE=${1:-caustics}; W=${2:-1920}; H=${3:-1080}; SPP=${4:-256}; PH=${5:-200000}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--no-cpu --no-others --scene $SCENE --width $W --height $H --spp $SPP --photons $PH"
+ARGS="--no-cpu --no-others --no-executed --scene $SCENE --width $W --height $H --spp $SPP --photons $PH"
 python3 bench.py --steps 3 --warmup 1 $ARGS > $OUT/bench.json 2> $OUT/bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 bench.py --steps 3 --warmup 1 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 pass() { name=$1; shift; timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o $name -- python3 bench.py --steps 1 --warmup 0 $ARGS > $OUT/$name.json 2> $OUT/$name.err; echo "$name done: $(tail -c 120 $OUT/$name.err | tr '\n' ' ')"; }
