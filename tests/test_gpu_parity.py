@@ -488,7 +488,9 @@ def test_streaming_work_counters_against_the_reference_counts(name, photons):
     assert c0["shadow_walks"] == oc[6] and c0["shadow_rays"] == oc[6] and c0["shadow_walks"] + c0["shadow_child_boxes"] <= oc[1]
     assert c0["shaded"] == oc[3]
     if photons:      # (without a map the reference still calls samplePhotons, which returns at once; the pipeline has no gather stage then)
-        assert c0["gather_queries"] == oc[7] and c0["gather_candidates"] == oc[4]
+        # the reference asks samplePhotons before its roulette decides whether the answer is used (include/raytracer.h:258-267); the pipeline asks only
+        # for vertices whose path goes on: never more queries than the reference, and most of them
+        assert 0.8 * oc[7] <= c0["gather_queries"] <= oc[7] and 0.8 * oc[4] <= c0["gather_candidates"] <= oc[4], (c0, oc)
     else:
         assert c0["gather_queries"] == 0 and oc[4] == 0
     assert c0["trace_content_boxes"] == 0 and c1["trace_content_boxes"] > 0

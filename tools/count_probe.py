@@ -16,4 +16,9 @@ rt.set_counters("stream")
 rt.run(w, h, min_samples=spp, max_samples=spp, f64=False)
 c = rt.stream_counters()
 n = w * h * spp
-print(name, w, h, spp, {k: round(v / n, 3) for k, v in c.items()})
+ms, _ = rt.last_render_ms()
+print(name, w, h, spp, "counted frame %.1f ms" % ms, rt.last_kernel_ms(), {k: round(v / n, 3) for k, v in c.items()})
+rt.set_counters(0)
+for _ in range(2):
+    rt.run(w, h, min_samples=spp, max_samples=spp, f64=False)
+print("plain frame %.1f ms" % rt.last_render_ms()[0], rt.last_kernel_ms())
