@@ -191,6 +191,7 @@ def roofline_of(scene_name, w, h, spp, photons, world, mode, local_samples, kern
         ex = dict(executed)
         ex["boxes"] = ex["trace_walks"] + ex["trace_child_boxes"] + ex["shadow_walks"] + ex["shadow_child_boxes"]
         ex["entity_tests"] = ex["trace_tris"] + ex["shadow_tris"]
+        ex["entity_boxes"] = ex.get("trace_entity_boxes", 0.0) + ex.get("shadow_entity_boxes", 0.0)   # references sorted by their own box before Entity::intersect
         r["executed_work"] = {"per_sample": ex, "source": "gi_set_counters(ctx, 2): per-lane counters of k_st_trace / k_st_shadow / k_st_gather over one extra, untimed frame"}
         if mix is not None:
             r["executed_work"]["vs_reference"] = {"boxes": ex["boxes"] / mix["V"] if mix["V"] else None, "entity_tests": ex["entity_tests"] / mix["T"] if mix["T"] else None,

@@ -61,7 +61,7 @@ _LIB = None
 # every symbol include/gi_hip.h and csrc/gi_host.h declare (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
-    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_last_kernel_ms", "gi_set_counters", "gi_get_counters", "gi_get_stream_counters", "gi_trace", "gi_visible",
+    "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_entity_boxes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_last_kernel_ms", "gi_set_counters", "gi_get_counters", "gi_get_stream_counters", "gi_trace", "gi_visible",
     "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
     "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
@@ -93,6 +93,7 @@ def lib():
     L.gi_set_render_mode.argtypes = [vp, C.c_int]
     L.gi_set_wide_nodes.argtypes = [vp, C.c_int]
     L.gi_set_content_culling.argtypes = [vp, C.c_int]
+    L.gi_set_entity_boxes.argtypes = [vp, C.c_int]
     L.gi_set_pool_slots.argtypes = [vp, C.c_int64]
     L.gi_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), _ip]
     L.gi_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -529,6 +530,10 @@ class RayTracer:
         """Skip children of the octree walk in whose sub-tree the ray cannot hit anything (default on); returns whether it is in use."""
         return bool(self._check(self.L.gi_set_content_culling(self.h, 1 if on else 0), "set_content_culling"))
 
+    def set_entity_boxes(self, on):
+        """Run the entity tests of a leaf only on the references whose own box the ray touches (default on); returns whether it is in use."""
+        return bool(self._check(self.L.gi_set_entity_boxes(self.h, 1 if on else 0), "set_entity_boxes"))
+
     def set_pool_slots(self, slots):
         self._check(self.L.gi_set_pool_slots(self.h, int(slots)), "set_pool_slots")
 
@@ -559,11 +564,11 @@ class RayTracer:
 
     STREAM_COUNTERS = ("trace_walks", "trace_records", "trace_child_boxes", "trace_content_boxes", "trace_leaves", "trace_tris", "trace_rays",
                        "shadow_walks", "shadow_records", "shadow_child_boxes", "shadow_content_boxes", "shadow_leaves", "shadow_tris", "shadow_rays",
-                       "gather_queries", "gather_candidates", "shaded")
+                       "gather_queries", "gather_candidates", "shaded", "trace_entity_boxes", "shadow_entity_boxes")
 
     def stream_counters(self):
         """gi_get_stream_counters: the executed work of the last frame rendered with set_counters("stream"), as a dict."""
-        out = (C.c_int64 * 17)()
+        out = (C.c_int64 * 19)()
         self._check(self.L.gi_get_stream_counters(self.h, out), "get_stream_counters")
         return dict(zip(self.STREAM_COUNTERS, [int(v) for v in out]))
 

@@ -125,6 +125,7 @@ struct Scene {
     const uint32_t* cuse;     // [n_wnode] children (slot bits) whose content box is worth testing (clearly smaller than their octant)
     const int32_t* leaf_refs;
     const LeafTri* leaf_tris; // [n_refs], parallel to leaf_refs
+    const double* leaf_boxes; // [n_refs][6] every reference's own box (min xyz, max xyz, widened): a ray that misses it cannot hit the entity; null = not used
     const TriGeom* tris;
     const TriShade* shade;
     const TriUV* tri_uv;      // [n_tri], only when n_tex > 0
@@ -499,6 +500,15 @@ GI_HD LeafTri leaf_tri_scalar(const LeafTri* rec)   // rec is wave-uniform
     g.tri = w[18]; g.matflags = (uint32_t)w[19];
     return g;
 }
+struct Box6 { double b[6]; };
+GI_HD Box6 leaf_box_scalar(const double* rec)   // rec is wave-uniform: the entity's box through the scalar cache
+{
+    typedef const __attribute__((address_space(4))) double* KD;
+    const KD d = (KD)rec;
+    Box6 r;
+    for (int k = 0; k < 6; k++) r.b[k] = d[k];
+    return r;
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------ textures (include/material.h:10-81)
@@ -639,6 +649,33 @@ GI_HD uint32_t content_cull(const float* cboxes, const uint32_t* cuse, int32_t n
     }
     return m;
 }
+// Entity boxes.  A leaf of the reference's octree holds up to a few dozen entities and RayTracer::trace / visible test every one of them
+// (include/raytracer.h:290-305,446-472); a ray through the leaf touches the boxes of one or two.  An entity whose own box -- widened by a margin
+// a billion times the rounding of a hit point -- the ray misses inside [0, tc] cannot report a hit (the hit point lies on the entity, at t > 0
+// and, for a shadow ray, before the light), so its test is skipped: the same hits in the same order, the same draws.  The lanes of a wave first
+// sort their leaf's references into a bit mask (a slab test of 24 flops per reference), then run Entity::intersect (~50 flops and a division)
+// on the few that are left -- the wave's loop is as long as its longest lane's, and that is now the lane with the most SURVIVORS.
+GI_HD bool entity_box_missed(const double* b, const Ray& r, double tc)
+{
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
+    double tn = 0.0, tf = tc;
+    for (int ax = 0; ax < 3; ax++) {
+        const double t0 = (b[ax] - o[ax]) * inv[ax], t1 = (b[3 + ax] - o[ax]) * inv[ax];
+        // a NaN (origin on a plane of an axis the ray does not move along: 0 * inf) is ignored by fmin / fmax: the origin is inside that slab
+        tn = fmax(tn, fmin(t0, t1));
+        tf = fmin(tf, fmax(t0, t1));
+    }
+    return !(tf >= tn);
+}
+// the references [first, first + cnt) of a leaf (cnt <= 32) whose boxes the ray touches, as a bit mask; all of them without the table
+GI_HD uint32_t entity_survivors(const Scene& S, int32_t first, int32_t cnt, const Ray& r, double tc)
+{
+    uint32_t m = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+    if (!S.leaf_boxes) return m;
+    for (int32_t j = 0; j < cnt; j++)
+        if (entity_box_missed(S.leaf_boxes + (size_t)(first + j) * 6, r, tc)) m &= ~(1u << j);
+    return m;
+}
 // bit k of the result: the k-th child in this ray's front-to-back order (slot k ^ a) exists and its box is hit in (tmin0, tmax0)
 GI_HD uint32_t wide_hits(const WNode* w, const Ray& r, const WRay& wr, double tmin0, double tmax0)
 {
@@ -696,13 +733,14 @@ GI_HD void wide_leaf_box(const WNode* w, int slot, double* lmin, double* lmax)  
 // records visited, child boxes tested from them (one per existing child: together with the root tests these are the reference's
 // BoundingBox::intersect calls when nothing is culled), content boxes tested, non-empty leaves met, entity tests.  A record source that does
 // not count compiles the ticks to nothing.
-struct WalkCnt { uint32_t walks, nodes, child_boxes, cull_tests, leaves, tris; };
+struct WalkCnt { uint32_t walks, nodes, child_boxes, cull_tests, leaves, tris, ent_boxes; };
 struct NoWalkCnt {
     GI_HDM void tick_walk() const {}
     GI_HDM void tick_node(uint32_t) const {}
     GI_HDM void tick_cull(uint32_t) const {}
     GI_HDM void tick_leaf() const {}
     GI_HDM void tick_tri() const {}
+    GI_HDM void tick_ebox(uint32_t) const {}
 };
 struct GlobalWide : NoWalkCnt {
     static constexpr bool kWide = true;
@@ -841,16 +879,39 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
 #ifdef GI_WAVE_UNIFORM_LEAVES
     int32_t first_u, cnt_u;
     if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
-        for (int32_t j = 0; j < cnt_u; j++) { GI_DIV(W, 4); test(leaf_tri_scalar(S.leaf_tris + first_u + j)); }
+        if (S.leaf_boxes) {
+            // every lane holds its own ray against the same entity: the record is only fetched when some lane's ray touches the entity's box
+            W.tick_ebox((uint32_t)cnt_u);
+            for (int32_t j = 0; j < cnt_u; j++) {
+                const Box6 bx = leaf_box_scalar(S.leaf_boxes + (size_t)(first_u + j) * 6);
+                const bool touch = !entity_box_missed(bx.b, ray, INFINITY);
+                if (__ballot(touch) == 0ull) continue;
+                const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
+                GI_DIV(W, 4);
+                if (touch) test(g);
+            }
+        } else
+            for (int32_t j = 0; j < cnt_u; j++) { GI_DIV(W, 4); test(leaf_tri_scalar(S.leaf_tris + first_u + j)); }
     } else
 #endif
-    for (int32_t j = 0; j < cnt; j += 2) {
-        const LeafTri g0 = S.leaf_tris[first + j];
-        const LeafTri g1 = S.leaf_tris[first + (j + 1 < cnt ? j + 1 : j)];
-        GI_DIV(W, 6);
-        test(g0);
-        if (j + 1 < cnt) { GI_DIV(W, 6); test(g1); }
-    }
+    if (S.leaf_boxes && cnt <= 32) {
+        // the references whose boxes the ray touches, in leaf order (one or two per leaf: a single record in flight)
+        uint32_t m = entity_survivors(S, first, cnt, ray, INFINITY);
+        W.tick_ebox((uint32_t)cnt);
+        while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            GI_DIV(W, 6);
+            test(S.leaf_tris[first + j]);
+        }
+    } else
+        for (int32_t j = 0; j < cnt; j += 2) {
+            const LeafTri g0 = S.leaf_tris[first + j];
+            const LeafTri g1 = S.leaf_tris[first + (j + 1 < cnt ? j + 1 : j)];
+            GI_DIV(W, 6);
+            test(g0);
+            if (j + 1 < cnt) { GI_DIV(W, 6); test(g1); }
+        }
     return !term;
 }
 template <int FEAT, class WN>
@@ -901,15 +962,34 @@ GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, doub
     int32_t first_u, cnt_u;
     if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
         bool hit = false;
+        const double tc = sqrt(mt) * (1.0 + 1e-9);
+        if (S.leaf_boxes) W.tick_ebox((uint32_t)cnt_u);
         for (int32_t j = 0; j < cnt_u; j++) {     // wave-uniform trip count: the record address stays scalar
+            bool touch = !hit;
+            if (S.leaf_boxes) {                   // (wave-uniform branch) fetch the record only when a lane that still looks for a blocker touches the entity's box
+                const Box6 bx = leaf_box_scalar(S.leaf_boxes + (size_t)(first_u + j) * 6);
+                touch = touch && !entity_box_missed(bx.b, ray, tc);
+                if (__ballot(touch) == 0ull) continue;
+            }
             const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
             GI_DIV(W, 4);
-            if (!hit) hit = blocks(g);
+            if (touch) hit = blocks(g);
             if (__ballot(!hit) == 0ull) break;
         }
         return hit;
     }
 #endif
+    if (S.leaf_boxes && cnt <= 32) {
+        uint32_t m = entity_survivors(S, first, cnt, ray, sqrt(mt) * (1.0 + 1e-9));   // a blocker lies before the light: 0 < |hit - o|^2 < mt
+        W.tick_ebox((uint32_t)cnt);
+        while (m) {
+            const int j = __builtin_ctz(m);
+            m &= m - 1;
+            GI_DIV(W, 6);
+            if (blocks(S.leaf_tris[first + j])) return true;
+        }
+        return false;
+    }
     for (int32_t j = 0; j < cnt; j++) {
         GI_DIV(W, 6);
         if (blocks(S.leaf_tris[first + j])) return true;

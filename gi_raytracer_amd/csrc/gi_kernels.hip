@@ -135,12 +135,13 @@ struct LdsWideT {
     static constexpr bool kCoop = false;
     static constexpr bool kCount = COUNT;
     // executed-work counters of this lane (gi_set_counters(ctx, 2)); an instance that does not count never touches them, and they are gone
-    mutable WalkCnt wc = {0, 0, 0, 0, 0, 0};
+    mutable WalkCnt wc = {0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void tick_walk() const { if constexpr (COUNT) wc.walks++; }
     __device__ __forceinline__ void tick_node(uint32_t exists) const { if constexpr (COUNT) { wc.nodes++; wc.child_boxes += (uint32_t)__builtin_popcount(exists & 0xffu); } }
     __device__ __forceinline__ void tick_cull(uint32_t n) const { if constexpr (COUNT) wc.cull_tests += n; }
     __device__ __forceinline__ void tick_leaf() const { if constexpr (COUNT) wc.leaves++; }
     __device__ __forceinline__ void tick_tri() const { if constexpr (COUNT) wc.tris++; }
+    __device__ __forceinline__ void tick_ebox(uint32_t n) const { if constexpr (COUNT) wc.ent_boxes += n; }
     const WNode* g;
     const float* cboxes;      // content boxes of the children (gi_device.h: content_cull), read through L1 / L2; null = no culling
     const uint32_t* cuse;
@@ -222,7 +223,7 @@ template <bool COUNT> struct LdsSrc<1, COUNT> { typedef LdsWideT<COUNT> type; st
                          static __device__ __forceinline__ type stage_with_boxes(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true); } };
 // what the streaming kernels executed in one frame (gi_get_stream_counters): per-lane WalkCnt sums of k_st_trace and k_st_shadow, the rays handed
 // to each, the gather's queries and the candidates they scanned
-struct StreamCounters { unsigned long long trace[6], trace_rays, shadow[6], shadow_rays, gather_queries, gather_cand; };
+struct StreamCounters { unsigned long long trace[7], trace_rays, shadow[7], shadow_rays, gather_queries, gather_cand; };
 __device__ __forceinline__ void flush_u64(unsigned long long* dst, unsigned long long v)
 {
     for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
@@ -231,7 +232,7 @@ __device__ __forceinline__ void flush_u64(unsigned long long* dst, unsigned long
 __device__ __forceinline__ void flush_walk_cnt(unsigned long long* dst6, const WalkCnt& w)
 {
     flush_u64(dst6 + 0, w.walks); flush_u64(dst6 + 1, w.nodes); flush_u64(dst6 + 2, w.child_boxes);
-    flush_u64(dst6 + 3, w.cull_tests); flush_u64(dst6 + 4, w.leaves); flush_u64(dst6 + 5, w.tris);
+    flush_u64(dst6 + 3, w.cull_tests); flush_u64(dst6 + 4, w.leaves); flush_u64(dst6 + 5, w.tris); flush_u64(dst6 + 6, w.ent_boxes);
 }
 
 // ================================================================================================= wavefront pipeline
@@ -1448,6 +1449,8 @@ struct gi_ctx {
     int32_t n_prange = 0;             // entries of d_pranges in use
     DevBuf<int32_t> d_refs;
     DevBuf<LeafTri> d_leaf_tris;
+    DevBuf<double> d_leaf_boxes;          // every leaf reference's own box (gi_device.h: entity_survivors)
+    bool entity_boxes = true;             // GI_ENTITY_BOXES=0: every entity of a leaf is tested, as the reference does
     DevBuf<TriGeom> d_tris;
     DevBuf<TriShade> d_shade;
     DevBuf<Mat> d_mats;
@@ -1571,6 +1574,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
     if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
     if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
+    if (const char* e = getenv("GI_ENTITY_BOXES")) c->entity_boxes = atoi(e) != 0;
     if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
     if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."
@@ -1627,6 +1631,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_tex_lut.upload(H.tex_lut));
     HIP_TRY(c, c->d_refs.upload(H.refs));
     HIP_TRY(c, c->d_leaf_tris.upload(H.leaf_tris));
+    HIP_TRY(c, c->d_leaf_boxes.upload(H.leaf_boxes));
     HIP_TRY(c, c->d_tris.upload(H.tris));
     HIP_TRY(c, c->d_shade.upload(H.shade));
     HIP_TRY(c, c->d_mats.upload(H.mats));
@@ -1636,6 +1641,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     Scene& S = c->S;
     S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.leaf_tris = c->d_leaf_tris.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
     S.mats = c->d_mats.p; S.lights = c->d_lights.p;
+    S.leaf_boxes = c->entity_boxes ? c->d_leaf_boxes.p : nullptr;
     S.n_node = H.n_node; S.n_tri = H.n_tri; S.n_light = H.n_light;
     for (int k = 0; k < 3; k++) { S.root_bmin[k] = H.tnodes[0].bmin[k]; S.root_bmax[k] = H.tnodes[0].bmax[k]; }
     S.n_wnode = (int32_t)H.wnodes.size();
@@ -1991,8 +1997,8 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             if (counting) {   // what this pass executed (tuning aid): cumulative counters, printed per pass
                 StreamCounters h;
                 if (hipMemcpy(&h, c->d_stream_cnt.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
-                    fprintf(stderr, "[cnt] trace rays %llu walks %llu records %llu boxes %llu cboxes %llu leaves %llu tris %llu | shadow rays %llu records %llu boxes %llu cboxes %llu leaves %llu tris %llu | gather q %llu cand %llu\n",
-                            h.trace_rays, h.trace[0], h.trace[1], h.trace[2], h.trace[3], h.trace[4], h.trace[5], h.shadow_rays, h.shadow[1], h.shadow[2], h.shadow[3], h.shadow[4], h.shadow[5], h.gather_queries, h.gather_cand);
+                    fprintf(stderr, "[cnt] trace rays %llu walks %llu records %llu boxes %llu cboxes %llu leaves %llu eboxes %llu tris %llu | shadow rays %llu records %llu boxes %llu cboxes %llu leaves %llu eboxes %llu tris %llu | gather q %llu cand %llu\n",
+                            h.trace_rays, h.trace[0], h.trace[1], h.trace[2], h.trace[3], h.trace[4], h.trace[6], h.trace[5], h.shadow_rays, h.shadow[1], h.shadow[2], h.shadow[3], h.shadow[4], h.shadow[6], h.shadow[5], h.gather_queries, h.gather_cand);
             }
         }
     }
@@ -2156,6 +2162,14 @@ int gi_set_content_culling(gi_ctx* c, int enable)
     return c->S.cboxes ? 1 : 0;
 }
 
+int gi_set_entity_boxes(gi_ctx* c, int enable)
+{
+    if (!c) return GI_E_INVALID;
+    c->entity_boxes = enable != 0;
+    c->S.leaf_boxes = (c->entity_boxes && c->have_scene) ? c->d_leaf_boxes.p : nullptr;
+    return c->S.leaf_boxes ? 1 : 0;
+}
+
 int gi_set_render_mode(gi_ctx* c, int mode)
 {
     if (!c || mode < 0 || mode > 2) return GI_E_INVALID;
@@ -2214,7 +2228,7 @@ int gi_set_counters(gi_ctx* c, int enable)
     c->count_stream = enable == 2;
     return GI_OK;
 }
-int gi_get_stream_counters(gi_ctx* c, int64_t* out17)
+int gi_get_stream_counters(gi_ctx* c, int64_t* out17 /* [19] */)
 {
     if (!c || !out17) return GI_E_INVALID;
     if (!c->d_stream_cnt.p) return fail(c, GI_E_STATE, "stream counters: no counted frame was rendered (gi_set_counters(ctx, 2), fixed sample count)");
@@ -2225,6 +2239,7 @@ int gi_get_stream_counters(gi_ctx* c, int64_t* out17)
     for (int k = 0; k < 6; k++) { out17[k] = (int64_t)h.trace[k]; out17[7 + k] = (int64_t)h.shadow[k]; }
     out17[6] = (int64_t)h.trace_rays; out17[13] = (int64_t)h.shadow_rays;
     out17[14] = (int64_t)h.gather_queries; out17[15] = (int64_t)h.gather_cand; out17[16] = (int64_t)c->stream_shaded;
+    out17[17] = (int64_t)h.trace[6]; out17[18] = (int64_t)h.shadow[6];
     return GI_OK;
 }
 int gi_get_counters(gi_ctx* c, int64_t* out8)

@@ -27,6 +27,7 @@ struct HostScene {
     std::vector<uint32_t> cuse;       // [n_wnode] children worth testing
     std::vector<int32_t> refs;
     std::vector<LeafTri> leaf_tris;
+    std::vector<double> leaf_boxes;   // [n_refs][6] the entity's own box, widened (gi_device.h: entity_box_missed), parallel to leaf_tris
     std::vector<TriGeom> tris;
     std::vector<TriShade> shade;
     std::vector<TriUV> tri_uv;
@@ -358,6 +359,24 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         lt.matflags = ((uint32_t)g.mat << 3) | g.flags;
     }
     if (H.leaf_tris.empty()) H.leaf_tris.resize(1);
+    {   // the entities' own boxes, leaf-reference order: what a ray has to touch before Entity::intersect can succeed
+        double extent = 0;
+        for (int ax = 0; ax < 3; ax++) extent = std::max(extent, d->node_bbox[3 + ax] - d->node_bbox[ax]);
+        const double margin = 1e-7 * std::max(extent, 1e-3);     // as for the content boxes: a hit point is off its entity by ~1e-16 of its coordinates
+        H.leaf_boxes.assign(std::max<size_t>(H.refs.size(), 1) * 6, 0.0);
+        for (size_t r = 0; r < H.refs.size(); r++) {
+            const int e = H.refs[r];
+            const double* P = d->tri_pos + (size_t)e * 9;
+            double* b = &H.leaf_boxes[r * 6];
+            if (d->ent_kind && d->ent_kind[e] == 1)
+                for (int ax = 0; ax < 3; ax++) { b[ax] = P[ax] - P[3] - margin; b[3 + ax] = P[ax] + P[3] + margin; }
+            else
+                for (int ax = 0; ax < 3; ax++) {
+                    b[ax] = std::min(P[ax], std::min(P[3 + ax], P[6 + ax])) - margin;
+                    b[3 + ax] = std::max(P[ax], std::max(P[3 + ax], P[6 + ax])) + margin;
+                }
+        }
+    }
     H.mats.resize((size_t)d->n_mat);
     for (int i = 0; i < d->n_mat; i++) {
         const double* m = d->mats + (size_t)i * 9;

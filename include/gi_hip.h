@@ -136,6 +136,10 @@ int gi_set_wide_nodes(gi_ctx*, int enable);
  * child is visited, as Octree::Node::intersectSorted does (include/octree.cpp:285-313).  Exists so that the two can be compared (frames are
  * identical bit for bit).  Returns 1 when culling is in use after the call (a scene is uploaded, its tree takes the wide walk), else 0.      */
 int gi_set_content_culling(gi_ctx*, int enable);
+/* Entity boxes: 1 (default) = the wide walk runs Entity::intersect only on the references of a leaf whose own (widened) box the ray touches; 0 = on
+ * every reference, as RayTracer::trace / visible do (include/raytracer.h:290-305,446-472).  A ray that misses an entity's box cannot hit the entity:
+ * same hits, same order, same frame bit for bit; exists so that the two can be compared.  Returns 1 when in use after the call.                  */
+int gi_set_entity_boxes(gi_ctx*, int enable);
 /* Upper bound on paths in flight in the wavefront pipeline (224 B each).  Default: as many as 80 % of the free HBM holds,
  * up to the whole frame (1080p x 256 spp = 531 M paths = 119 GB).                                                           */
 int gi_set_pool_slots(gi_ctx*, int64_t slots);
@@ -153,12 +157,13 @@ int gi_last_kernel_ms(gi_ctx*, float* out10);
  * gi_set_counters(ctx, 2): what the streaming kernels EXECUTE -- the frame is rendered by the pipeline that is benchmarked, its walks count per
  * lane, and gi_get_stream_counters gives out17 = k_st_trace: [0] walks begun (root box tests), [1] wide records visited, [2] child boxes tested
  * from them, [3] content boxes tested, [4] non-empty leaves met, [5] entity tests, [6] rays handed to the kernel; k_st_shadow: [7..12] the same
- * six, [13] shadow segments; [14] gather queries, [15] photon candidates they scanned, [16] shaded hits.  With content-box culling off,
- * [0] + [2] and [5] are the reference's node visits and entity tests of trace() exactly.  Covers fixed-sample-count frames of triangle scenes
+ * six, [13] shadow segments; [14] gather queries, [15] photon candidates they scanned, [16] shaded hits; [17] / [18] references sorted by their
+ * entity box in k_st_trace / k_st_shadow (out must hold 19 values).  With content-box culling and entity boxes off, [5] is the reference's count of
+ * entity tests in trace() exactly, and [0] the number of its trace() calls.  Covers fixed-sample-count frames of triangle scenes
  * without spheres, fog or textures (the BASELINE scenes); other scenes get GI_E_STATE.  0 = off (default).                                  */
 int gi_set_counters(gi_ctx*, int mode);
 int gi_get_counters(gi_ctx*, int64_t* out8);
-int gi_get_stream_counters(gi_ctx*, int64_t* out17);
+int gi_get_stream_counters(gi_ctx*, int64_t* out19);
 
 /* Function-level entry points (parity tests and the C++ API's public methods).  Host pointers.
  * replaces RayTracer::trace (include/raytracer.h:382-478): rays [n][6] origin + unit dir -> hit, entity, res [n][8]        */

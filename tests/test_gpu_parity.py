@@ -160,8 +160,8 @@ def test_schedule_knobs_change_nothing(name, monkeypatch):
     to the put-off segment.  GI_COOP_FACTOR moves the finisher between one path per lane, per group of 16 lanes and per wave."""
     scene = pc.two_light_scene(name.endswith("glass")) if name.startswith("two_lights") else pc.load_scene(name)   # two lights: one put-off query per light
     frames = []
-    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}):
-        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR"):
+    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}, {"GI_ENTITY_BOXES": "0"}):
+        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR", "GI_ENTITY_BOXES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -449,7 +449,7 @@ def test_textured_glass_scene_at_256_spp_is_inside_the_contract():
 
 @pytest.mark.parametrize("name,photons", [("cornell", 0), ("caustics", 5000), ("teapot", 3000)])
 def test_streaming_work_counters_against_the_reference_counts(name, photons):
-    """gi_set_counters(ctx, 2): what the streaming kernels execute.  With content-box culling OFF the walk of k_st_trace meets the leaves of
+    """gi_set_counters(ctx, 2): what the streaming kernels execute.  With content-box culling and entity boxes OFF the walk of k_st_trace meets the leaves of
     Octree::intersectSorted's list in the same order and stops after the same one, so it tests exactly the entities RayTracer::trace tests
     (include/raytracer.h:446-472): its entity tests equal the oracle's T_trace; the any-hit shadow walk stops at the first blocker like the
     reference's candidate loop (include/raytracer.h:290-305), in front-to-back instead of DFS order: T_shadow within a few per cent.  Box tests stay at or below the reference's, which walks the whole
@@ -470,14 +470,16 @@ def test_streaming_work_counters_against_the_reference_counts(name, photons):
     rt.set_counters("stream")
     try:
         rt.set_content_culling(False)
+        assert not rt.set_entity_boxes(False)
         a = rt.run(w, h, min_samples=spp, max_samples=spp)
         c0 = rt.stream_counters()
-        assert rt.set_content_culling(True)
+        assert rt.set_content_culling(True) and rt.set_entity_boxes(True)
         b = rt.run(w, h, min_samples=spp, max_samples=spp)
         c1 = rt.stream_counters()
     finally:
         rt.set_counters(0)
         rt.set_content_culling(True)
+        rt.set_entity_boxes(True)
     assert np.array_equal(a.view(np.uint64), plain.view(np.uint64)) and np.array_equal(b.view(np.uint64), plain.view(np.uint64))   # counting changes nothing
     # trace(): one root test per call (a ray that misses the root box -- a camera ray outside the scene -- begins a walk and tests nothing else)
     assert c0["trace_walks"] == oc[5] and c0["trace_rays"] >= oc[5] and c0["trace_walks"] + c0["trace_child_boxes"] <= oc[0], (c0, oc)
@@ -493,7 +495,7 @@ def test_streaming_work_counters_against_the_reference_counts(name, photons):
         assert 0.8 * oc[7] <= c0["gather_queries"] <= oc[7] and 0.8 * oc[4] <= c0["gather_candidates"] <= oc[4], (c0, oc)
     else:
         assert c0["gather_queries"] == 0 and oc[4] == 0
-    assert c0["trace_content_boxes"] == 0 and c1["trace_content_boxes"] > 0
+    assert c0["trace_content_boxes"] == 0 and c1["trace_content_boxes"] > 0 and c0["trace_entity_boxes"] == 0 and c1["trace_entity_boxes"] > 0
     # culling on: same rays, same shaded hits and gathers, fewer boxes and entity tests
     for k in ("trace_rays", "trace_walks", "shadow_rays", "shaded", "gather_queries", "gather_candidates"):
         assert c1[k] == c0[k], k

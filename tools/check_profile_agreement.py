@@ -24,8 +24,14 @@ name = max(stages, key=stages.get)                        # the dominant stage (
 k = [v for n, v in parts.items() if n.split("<")[0] == "k_st_" + name or (name == "shade" and "shadow" not in stages and n.startswith("k_st_shadow"))]
 print("dominant k_st_%s: rocprof %.1f ms, bench.py %.1f ms" % (name, sum(k), stages[name]))
 if "per_kernel" in roof:
-    sq = json.load(open(tag + "_sq_pmc.json"))["per_kernel"]
-    hb = json.load(open(tag + "_hbm_traffic.json"))["per_kernel"]
+    # the counter summaries the line says it used (relative to the repository root), else this tag's
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ev = roof.get("evidence", {})
+    sq_path = os.path.join(root, ev["sq_counters"]) if ev.get("sq_counters") and os.path.exists(os.path.join(root, ev["sq_counters"])) else tag + "_sq_pmc.json"
+    hb_path = os.path.join(root, ev["hbm_traffic"]) if ev.get("hbm_traffic") and os.path.exists(os.path.join(root, ev["hbm_traffic"])) else tag + "_hbm_traffic.json"
+    print("counters: %s, %s" % (os.path.relpath(sq_path, root), os.path.relpath(hb_path, root)))
+    sq = json.load(open(sq_path))["per_kernel"]
+    hb = json.load(open(hb_path))["per_kernel"]
     fam = lambda table, f, get: sum(get(v) for n, v in table.items() if n.split("<")[0] == f and get(v) is not None)
     bad = 0
     for f, e in roof["per_kernel"].items():
