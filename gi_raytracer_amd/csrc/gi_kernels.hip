@@ -995,7 +995,9 @@ __global__ __launch_bounds__(256) void k_st_compact(Scene S, CompactJob job, con
 // scans them from there -- a broadcast LDS read per candidate instead of an L2 round trip per lane.  Waves that straddle a leaf
 // boundary take the per-lane walk.  Both run g_key / g_acc / g_end, i.e. the same arithmetic in the same order.
 #define GI_GCHUNK 64
+#ifndef GI_GATHER_WAVES
 #define GI_GATHER_WAVES 4      // waves per SIMD the gather kernel is compiled for (launch bound)
+#endif
 // Pass 1 of the cooperative path keeps a lane's 32 smallest keys sorted in 32 registers and folds the candidates in 32 at a time:
 // sort the 32 new keys (odd-even merge sort network), take min(best[i], new[31 - i]) -- the 32 smallest of the 64, as a bitonic sequence --
 // and merge.  18 branch-free instructions per candidate; the LDS heap costs ~55, because with 64 lanes some lane always has to
