@@ -62,7 +62,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
     "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_entity_boxes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_last_kernel_ms", "gi_set_counters", "gi_get_counters", "gi_get_stream_counters", "gi_trace", "gi_visible",
-    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
+    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_debug_sort_pairs", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
     "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_texture", "gih_add_material_tex", "gih_load_png", "gih_free",
@@ -109,6 +109,7 @@ def lib():
     L.gi_halton_sample.argtypes = [vp, C.c_int32, _up, _up, C.POINTER(C.c_float)]
     L.gi_halton_index.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _up, _up]
     L.gi_debug_leaf_order.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _ip]
+    L.gi_debug_sort_pairs.argtypes = [vp, C.c_int32, _up, _up, C.c_int32, C.c_int32, _up, _up]
     L.gi_kat.argtypes = [vp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp]
     L.gi_clear_photons.argtypes = [vp]
     L.gi_group_clear_photons.argtypes = [vp]
@@ -613,6 +614,13 @@ class RayTracer:
         out = np.zeros((len(a), 3))
         self._check(self.L.gi_kat(self.h, self.KAT[what], len(a), _p(a), a.shape[1], _p(out)), "kat")
         return out
+
+    def sort_pairs(self, keys, vals, begin_bit=0, end_bit=32):
+        """gi_debug_sort_pairs: the pipeline's radix sort on caller data (stable, by bits [begin_bit, end_bit) of the key)."""
+        k = np.ascontiguousarray(keys, np.uint32); v = np.ascontiguousarray(vals, np.uint32)
+        ko = np.zeros_like(k); vo = np.zeros_like(v)
+        self._check(self.L.gi_debug_sort_pairs(self.h, len(k), _p(k, _up), _p(v, _up), begin_bit, end_bit, _p(ko, _up), _p(vo, _up)), "sort_pairs")
+        return ko, vo
 
     def leaf_order(self, rays, cap=256):
         """Octree::intersectSorted as the device walk produces it: per ray the pre-order indices of the non-empty leaves in visiting order."""

@@ -1486,6 +1486,9 @@ struct gi_ctx {
     DevBuf<uint32_t> d_segs;             // segment start of every producer workgroup
     DevBuf<uint32_t> d_ck[2], d_cv;      // continuing-ray sort: keys in / out, unsorted slots
     DevBuf<unsigned char> d_sort_tmp;
+    DevBuf<uint32_t> d_rs_hist;          // gi_sort.inc: [digit][workgroup] counters of a radix pass
+    bool rs_attr_set = false;
+    bool own_sort = false;               // GI_OWN_SORT=1: the two sorts of a pass through gi_sort.inc instead of hipcub::DeviceRadixSort (rocPRIM), which is the faster of the two
     StreamCtl* h_ctl = nullptr;
     size_t lbuf_bytes_max = (size_t)16 << 30;
     // per-stage device time of the last streaming frame (HIP events around every launch, same stream)
@@ -1545,6 +1548,7 @@ static int install_pleaf_rank(gi_ctx* c)
     return GI_OK;
 }
 
+#include "gi_sort.inc"
 #include "gi_photon_build.inc"
 
 extern "C" {
@@ -1576,6 +1580,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
     if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
     if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
+    if (const char* e = getenv("GI_OWN_SORT")) c->own_sort = atoi(e) != 0;
     if (const char* e = getenv("GI_ENTITY_BOXES")) c->entity_boxes = atoi(e) != 0;
     if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
@@ -1847,7 +1852,9 @@ static int stream_alloc(gi_ctx* c, uint32_t P)
     {
         size_t need = 0;
         HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0, 32, c->stream));
+        need = std::max(need, (size_t)P * 8);   // gi_sort.inc ping-pongs through one more copy of keys and values
         if (c->d_sort_tmp.n < need) HIP_TRY(c, c->d_sort_tmp.alloc(need));
+        if (!c->d_rs_hist.p) HIP_TRY(c, c->d_rs_hist.alloc((size_t)GI_RS_MAXBINS * GI_MAX_PRODUCER_BLOCKS));
     }
     if (!c->d_ctl.p) HIP_TRY(c, c->d_ctl.alloc(1));
     if (!c->h_ctl) HIP_TRY(c, hipHostMalloc((void**)&c->h_ctl, sizeof(StreamCtl), hipHostMallocDefault));
@@ -1977,7 +1984,12 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             while ((1u << bits) <= (uint32_t)c->S.n_pleaf) bits++;   // keys 0 .. n_pleaf
             size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
-            HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
+            if (c->own_sort) {
+                uint32_t* const tk = reinterpret_cast<uint32_t*>(c->d_sort_tmp.p);
+                int rc = rs_sort_pairs(c, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, tk, tk + n_gather, n_gather, nullptr, 0, bits, c->d_rs_hist.p);
+                if (rc) return rc;
+            } else
+                HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
             stage_end(c);
             stage_begin(c, STG_GATHER); hipLaunchKernelGGL(counting ? (k_st_gather<true>) : (k_st_gather<false>), dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf, sc); stage_end(c);
             launches += 2;
@@ -1987,7 +1999,11 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
             size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
-            if (c->sort_cont) HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, c->sort_lo_bit, 27, st));
+            if (c->sort_cont && c->own_sort) {
+                uint32_t* const tk = reinterpret_cast<uint32_t*>(c->d_sort_tmp.p);
+                int rc = rs_sort_pairs(c, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, tk, tk + n_cont, n_cont, nullptr, c->sort_lo_bit, 27, c->d_rs_hist.p);
+                if (rc) return rc;
+            } else if (c->sort_cont) HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, c->sort_lo_bit, 27, st));
             else HIP_TRY(c, hipMemcpyAsync(qcont_out, c->d_cv.p, (size_t)n_cont * 4, hipMemcpyDeviceToDevice, st));   // GI_SORT_CONT=0: queue order (tuning aid)
             stage_end(c);
             launches++;
@@ -2472,6 +2488,24 @@ int gi_debug_photon_tables(gi_ctx* c, int32_t* n_node, int32_t* n_range, int32_t
     if (ranges2) HIP_TRY(c, hipMemcpy(ranges2, S.pranges, (size_t)c->n_prange * sizeof(PRange), hipMemcpyDeviceToHost));
     if (pos3 && S.n_photon) HIP_TRY(c, hipMemcpy(pos3, S.ph_pos, (size_t)S.n_photon * 24, hipMemcpyDeviceToHost));
     if (dircol6 && S.n_photon) HIP_TRY(c, hipMemcpy(dircol6, S.ph_dircol, (size_t)S.n_photon * 48, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_debug_sort_pairs(gi_ctx* c, int32_t n, const uint32_t* keys, const uint32_t* vals, int32_t begin_bit, int32_t end_bit, uint32_t* keys_out, uint32_t* vals_out)
+{
+    if (!c || n < 0 || begin_bit < 0 || end_bit > 32 || end_bit <= begin_bit || (n && (!keys || !vals || !keys_out || !vals_out))) return GI_E_INVALID;
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<uint32_t> d[6], d_hist;
+    for (int k = 0; k < 6; k++) HIP_TRY(c, d[k].alloc((size_t)n));
+    HIP_TRY(c, d_hist.alloc((size_t)GI_RS_MAXBINS * GI_MAX_PRODUCER_BLOCKS));
+    HIP_TRY(c, hipMemcpy(d[0].p, keys, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d[1].p, vals, (size_t)n * 4, hipMemcpyHostToDevice));
+    int rc = rs_sort_pairs(c, d[0].p, d[2].p, d[1].p, d[3].p, d[4].p, d[5].p, (uint32_t)n, nullptr, begin_bit, end_bit, d_hist.p);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(keys_out, d[2].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(vals_out, d[3].p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GI_OK;
 }
 

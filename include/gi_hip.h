@@ -231,6 +231,9 @@ int gi_group_render_device(gi_group*, const gi_render_params*, int32_t stripe_h,
  * DESIGN.md "RNG contract"): in = seed high 32 bits, seed low 32 bits, stream, depth, purpose, a, b (integers carried in doubles),
  * out = the draw, the stream key's high and low 32 bits.  in [n][in_stride] (arguments in the order given), out3 [n][3].  */
 int gi_debug_leaf_order(gi_ctx*, int32_t n, const double* rays, int32_t cap, int32_t* leaf_out, int32_t* n_out);
+/* gi_debug_sort_pairs: the pipeline's own radix sort (gi_sort.inc: the gather queries by photon-map leaf, the continuing rays by coherence key) on
+ * caller data -- n (key, value) pairs sorted by bits [begin_bit, end_bit) of the key, stable.  Host pointers.                                */
+int gi_debug_sort_pairs(gi_ctx*, int32_t n, const uint32_t* keys, const uint32_t* vals, int32_t begin_bit, int32_t end_bit, uint32_t* keys_out, uint32_t* vals_out);
 int gi_kat(gi_ctx*, int32_t what, int32_t n, const double* in, int32_t in_stride, double* out3);
 
 

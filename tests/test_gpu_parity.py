@@ -160,8 +160,8 @@ def test_schedule_knobs_change_nothing(name, monkeypatch):
     to the put-off segment.  GI_COOP_FACTOR moves the finisher between one path per lane, per group of 16 lanes and per wave."""
     scene = pc.two_light_scene(name.endswith("glass")) if name.startswith("two_lights") else pc.load_scene(name)   # two lights: one put-off query per light
     frames = []
-    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}, {"GI_ENTITY_BOXES": "0"}):
-        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR", "GI_ENTITY_BOXES"):
+    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}, {"GI_ENTITY_BOXES": "0"}, {"GI_OWN_SORT": "1"}):
+        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR", "GI_ENTITY_BOXES", "GI_OWN_SORT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -282,6 +282,24 @@ def test_pool_refills_without_photon_map(name):
     finally:
         rt.set_pool_slots(1 << 30)
     assert b.shape == a.shape
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 8191, 8192, 8193, 100003, 2500000, 5 * 8192 * 256 + 777])
+def test_own_radix_sort_is_a_stable_sort(rt0, n):
+    """gi_sort.inc through gi_debug_sort_pairs: the pipeline's radix sort (gather queries by photon-map leaf, continuing rays by coherence key) on
+    random pairs -- the result is the stable sort of the pairs by the selected key bits (so: a permutation, every value exactly once), for the bit
+    ranges the pipeline uses (15-17 bits from 0, 27 bits, a raised lowest bit) and for all 32 bits; sizes around the 8 192-pair tile and beyond one
+    workgroup's share."""
+    rs = np.random.RandomState(n % 1000)
+    vals = np.arange(n, dtype=np.uint32)
+    for (lo, hi), kmax in (((0, 15), 27000), ((0, 17), 72738), ((0, 27), 2 ** 27), ((6, 27), 2 ** 27), ((0, 32), 2 ** 32), ((0, 3), 8)):
+        keys = rs.randint(0, kmax, n, dtype=np.uint64).astype(np.uint32)
+        if n > 1000:
+            keys[rs.randint(0, n, n // 3)] = keys[0]            # a heavy digit: one bin takes a third of the input
+        ko, vo = rt0.sort_pairs(keys, vals, lo, hi)
+        sel = (keys.astype(np.uint64) >> lo) & ((1 << (hi - lo)) - 1)
+        order = np.argsort(sel, kind="stable")
+        assert np.array_equal(vo, vals[order]) and np.array_equal(ko, keys[order]), (n, lo, hi)
 
 
 def test_gather_resolves_float_key_ties_exactly():
