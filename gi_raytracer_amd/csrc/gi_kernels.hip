@@ -1488,7 +1488,7 @@ struct gi_ctx {
     DevBuf<unsigned char> d_sort_tmp;
     DevBuf<uint32_t> d_rs_hist;          // gi_sort.inc: [digit][workgroup] counters of a radix pass
     bool rs_attr_set = false;
-    bool own_sort = false;               // GI_OWN_SORT=1: the two sorts of a pass through gi_sort.inc instead of hipcub::DeviceRadixSort (rocPRIM), which is the faster of the two
+    bool own_sort = true;                // GI_OWN_SORT=0: the two sorts of a pass through hipcub::DeviceRadixSort (rocPRIM) instead of gi_sort.inc
     StreamCtl* h_ctl = nullptr;
     size_t lbuf_bytes_max = (size_t)16 << 30;
     // per-stage device time of the last streaming frame (HIP events around every launch, same stream)
