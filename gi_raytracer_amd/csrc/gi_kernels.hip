@@ -7,7 +7,6 @@
 // Host side of this file: device layouts (8 direction-ordered copies of the octree, leaf-ordered photons, Halton tables)
 // and the gi_* entry points.  No CPU fallback exists: every entry needs a HIP device.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <array>
@@ -1488,7 +1487,6 @@ struct gi_ctx {
     DevBuf<unsigned char> d_sort_tmp;
     DevBuf<uint32_t> d_rs_hist;          // gi_sort.inc: [digit][workgroup] counters of a radix pass
     bool rs_attr_set = false;
-    bool own_sort = true;                // GI_OWN_SORT=0: the two sorts of a pass through hipcub::DeviceRadixSort (rocPRIM) instead of gi_sort.inc
     StreamCtl* h_ctl = nullptr;
     size_t lbuf_bytes_max = (size_t)16 << 30;
     // per-stage device time of the last streaming frame (HIP events around every launch, same stream)
@@ -1580,7 +1578,6 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
     if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
     if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
-    if (const char* e = getenv("GI_OWN_SORT")) c->own_sort = atoi(e) != 0;
     if (const char* e = getenv("GI_ENTITY_BOXES")) c->entity_boxes = atoi(e) != 0;
     if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
@@ -1850,9 +1847,7 @@ static int stream_alloc(gi_ctx* c, uint32_t P)
     if (!c->d_segs.p) HIP_TRY(c, c->d_segs.alloc(GI_MAX_PRODUCER_BLOCKS));
     if (c->d_cv.n < P) HIP_TRY(c, c->d_cv.alloc(P));
     {
-        size_t need = 0;
-        HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)P, 0, 32, c->stream));
-        need = std::max(need, (size_t)P * 8);   // gi_sort.inc ping-pongs through one more copy of keys and values
+        const size_t need = (size_t)P * 8;   // gi_sort.inc ping-pongs through one more copy of keys and values
         if (c->d_sort_tmp.n < need) HIP_TRY(c, c->d_sort_tmp.alloc(need));
         if (!c->d_rs_hist.p) HIP_TRY(c, c->d_rs_hist.alloc((size_t)GI_RS_MAXBINS * GI_MAX_PRODUCER_BLOCKS));
     }
@@ -1982,14 +1977,12 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         if (c->S.n_pnode > 0 && n_gather > 0) {
             int bits = 1;
             while ((1u << bits) <= (uint32_t)c->S.n_pleaf) bits++;   // keys 0 .. n_pleaf
-            size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
-            if (c->own_sort) {
+            {
                 uint32_t* const tk = reinterpret_cast<uint32_t*>(c->d_sort_tmp.p);
-                int rc = rs_sort_pairs(c, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, tk, tk + n_gather, n_gather, nullptr, 0, bits, c->d_rs_hist.p);
+                const int rc = rs_sort_pairs(c, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, tk, tk + n_gather, n_gather, nullptr, 0, bits, c->d_rs_hist.p);
                 if (rc) return rc;
-            } else
-                HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_gk[0].p, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, (int)n_gather, 0, bits, st));
+            }
             stage_end(c);
             stage_begin(c, STG_GATHER); hipLaunchKernelGGL(counting ? (k_st_gather<true>) : (k_st_gather<false>), dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf, sc); stage_end(c);
             launches += 2;
@@ -1997,13 +1990,12 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         n_cont = c->h_ctl->n_cont;
         n_free = c->h_ctl->n_free;
         if (n_cont > 0) {   // continuing rays in coherence order for the next trace pass
-            size_t tmp_bytes = c->d_sort_tmp.n;
             stage_begin(c, STG_SORT);
-            if (c->sort_cont && c->own_sort) {
+            if (c->sort_cont) {
                 uint32_t* const tk = reinterpret_cast<uint32_t*>(c->d_sort_tmp.p);
-                int rc = rs_sort_pairs(c, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, tk, tk + n_cont, n_cont, nullptr, c->sort_lo_bit, 27, c->d_rs_hist.p);
+                const int rc = rs_sort_pairs(c, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, tk, tk + n_cont, n_cont, nullptr, c->sort_lo_bit, 27, c->d_rs_hist.p);
                 if (rc) return rc;
-            } else if (c->sort_cont) HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp.p, tmp_bytes, c->d_ck[0].p, c->d_ck[1].p, c->d_cv.p, qcont_out, (int)n_cont, c->sort_lo_bit, 27, st));
+            }
             else HIP_TRY(c, hipMemcpyAsync(qcont_out, c->d_cv.p, (size_t)n_cont * 4, hipMemcpyDeviceToDevice, st));   // GI_SORT_CONT=0: queue order (tuning aid)
             stage_end(c);
             launches++;
@@ -2449,11 +2441,8 @@ int gi_trace_photons(gi_ctx* c, int32_t count, int32_t max_depth, uint64_t seed,
     HIP_TRY(c, d_p.alloc((size_t)total)); HIP_TRY(c, d_s.alloc((size_t)total)); HIP_TRY(c, d_t.alloc((size_t)total)); HIP_TRY(c, d_x.alloc((size_t)total));
     hipLaunchKernelGGL(k_emit, GI_GRID(total), 0, c->stream, c->S, count, max_depth, seed, d_p.p, d_s.p, d_t.p);
     // stored photons in (photon index, light) order = the order one reference thread appends them (include/raytracer.h:593-706)
-    size_t tb = 0;
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_s.p, d_x.p, (int)total, c->stream));
-    DevBuf<unsigned char> d_tmp;
-    HIP_TRY(c, d_tmp.alloc(tb));
-    HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(d_tmp.p, tb, d_s.p, d_x.p, (int)total, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_x.p, d_s.p, (size_t)total * 4, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, c->stream, reinterpret_cast<uint32_t*>(d_x.p), (uint32_t)total);   // exclusive prefix sums, in place (gi_sort.inc)
     int32_t last_x = 0, last_s = 0;
     HIP_TRY(c, hipMemcpyAsync(&last_x, d_x.p + (total - 1), 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&last_s, d_s.p + (total - 1), 4, hipMemcpyDeviceToHost, c->stream));
