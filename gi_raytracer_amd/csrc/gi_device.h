@@ -113,6 +113,7 @@ struct alignas(128) PNode { // 128 B: photon octree node; the 8 children of a no
         struct { double lo2[3], hi2[3]; } in;                 // inner nodes: the high-side children span [lo2, hi2] (= [min + .5 d, mid + .5 d],
     } u;                                                      // include/photonMap.cpp:139-149), child 7 [mid, max], low-side children [min, mid]
 };
+struct PDescent { double mid[3]; int32_t first_child, pad; };   // what the descent of getBounds decides by; the boxes it checks stay in PNode
 struct PRange { int32_t first, count; };   // photons are stored leaf by leaf in the reference's DFS order
 struct HaltonDim { uint32_t P, n, off; float scale; uint32_t mlo, mhi, pad[2]; };   // (mhi:mlo) = floor((2^64 - 1) / P) + 1: x / P = hi64(x * m) for every 32-bit x
 struct FogD { double pos[3], size[3], col[3], d, sc, bmin[3], bmax[3]; int32_t grid_off, grid_n; };   // HeightFog, include/atmosphere.h:30-83
@@ -132,6 +133,7 @@ struct Scene {
     const Mat* mats;
     const LightD* lights;
     const PNode* pnodes;
+    const struct PDescent* pdescent;   // [n_pnode] split point and first child only (32 B: the whole table stays in L2), for gather_find_leaf_fast; null = not used
     const int32_t* pleaf_rank;   // [n_pnode] rank of a leaf among the leaves with candidate photons (the gather queries' sort key), -1 for every other node
     const int32_t* prank_leaf;   // [n_pleaf] its inverse
     int32_t n_pleaf;             // leaves with candidates
@@ -153,6 +155,7 @@ struct Scene {
     int32_t n_fog;
     double ambient[3];
     double root_bmin[3], root_bmax[3];   // box of octree node 0 (kernel argument: no memory round trip before a walk starts)
+    double pmap_bmin[3], pmap_bmax[3];   // box of the photon map's root (gather_find_leaf_fast)
 };
 
 struct Counters { unsigned long long v_trace, v_shadow, tri, shaded, pcand, traces, shadows, gathers; };
@@ -1451,6 +1454,32 @@ GI_HD int32_t gather_find_leaf(const Scene& S, V3 pos)
         node = ch;
     }
     return node;
+}
+// The same descent for the bulk of the queries (k_st_compact: one per gather query of a pass).  PhotonMap::Node::getBounds picks the child by comparing the
+// position with the split point and then asks whether that child's box contains it (include/photonMap.cpp:115-134).  The child's box is made of the
+// parent's planes, so the answer can only be "no" when the position lies within rounding (an ulp of the box's size) of the split point or of the map's own
+// faces -- the three forms of "the middle" the reference computes differ in the last bit.  A query that keeps clear of every split plane on its way by
+// 1e-12 of the map's extent, and of the map's faces, is inside every box on the way: it needs the 32-byte split records only (2.3 MB for the benchmark's
+// map: L2-resident, where the 128-byte nodes are not).  Any other query (returns -2) takes gather_find_leaf.  Same leaf by construction.
+GI_HD int32_t gather_find_leaf_fast(const Scene& S, V3 pos)
+{
+    const double p[3] = {pos.x, pos.y, pos.z};
+    double ext = 0.0;
+    for (int ax = 0; ax < 3; ax++) ext = fmax(ext, S.pmap_bmax[ax] - S.pmap_bmin[ax]);
+    const double eps = 1e-12 * ext;
+    for (int ax = 0; ax < 3; ax++) if (!(p[ax] > S.pmap_bmin[ax] + eps && p[ax] < S.pmap_bmax[ax] - eps)) return -2;
+    int32_t node = 0;
+    for (;;) {
+        const PDescent nd = S.pdescent[node];
+        if (nd.first_child < 0) return node;
+        int k = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            const double dlt = p[ax] - nd.mid[ax];
+            if (!(fabs(dlt) > eps)) return -2;                       // too close to a split plane to skip the box test (NaN lands here too)
+            if (dlt > 0.0) k |= ax == 0 ? 1 : (ax == 2 ? 2 : 4);     // x = bit 0, z = bit 1, y = bit 2
+        }
+        node = nd.first_child + k;
+    }
 }
 // Visit every candidate photon of a leaf's range list.  Positions are fetched four at a time before any of them is used, so the
 // four loads are in flight together instead of one L2 round trip per photon (the loop is latency-bound otherwise).

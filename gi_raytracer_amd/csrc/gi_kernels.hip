@@ -921,6 +921,15 @@ __global__ __launch_bounds__(1024) void k_pleaf_rank(const PNode* nodes, int32_t
     }
     if (threadIdx.x == 0) *n_out = base;
 }
+__global__ __launch_bounds__(256) void k_pdescent(const PNode* nodes, int32_t n, PDescent* out)
+{
+    const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    PDescent d;
+    d.mid[0] = nodes[i].mid[0]; d.mid[1] = nodes[i].mid[1]; d.mid[2] = nodes[i].mid[2];
+    d.first_child = nodes[i].first_child; d.pad = 0;
+    out[i] = d;
+}
 struct CompactStream { const uint32_t* src; uint32_t* dst; int width; };
 struct CompactJob {
     CompactStream st[5];    // streams of queue A (e.g. slot + key), then queue B, queue C: n_streams[q] streams each
@@ -963,7 +972,8 @@ __global__ __launch_bounds__(256) void k_st_compact(Scene S, CompactJob job, con
             if (q == job.gather_queue) {
                 const CompactStream& sl = job.st[stream0];
                 const double* pos = reinterpret_cast<const double*>(job.st[stream0 + 1].src) + from * 3;
-                const int32_t leaf = gather_find_leaf(S, v3(pos[0], pos[1], pos[2]));
+                int32_t leaf = S.pdescent ? gather_find_leaf_fast(S, v3(pos[0], pos[1], pos[2])) : -2;
+                if (leaf == -2) leaf = gather_find_leaf(S, v3(pos[0], pos[1], pos[2]));
                 sl.dst[to] = sl.src[from];
                 const int32_t rank = leaf < 0 ? -1 : S.pleaf_rank[leaf];
                 job.st[stream0 + 1].dst[to] = rank < 0 ? (uint32_t)S.n_pleaf : (uint32_t)rank;   // the key past the last leaf: nothing to gather
@@ -1461,6 +1471,8 @@ struct gi_ctx {
     DevBuf<PNode> d_pnodes;
     DevBuf<PRange> d_pranges;
     DevBuf<int32_t> d_pleaf_rank, d_prank_leaf, d_n_pleaf;
+    DevBuf<PDescent> d_pdescent;
+    bool fast_descent = true;         // GI_FAST_DESCENT=0: every gather query walks the full photon-octree records
     DevBuf<double> d_ph_pos, d_ph_dircol;
     DevBuf<HaltonDim> d_hdims;
     DevBuf<uint16_t> d_htable;
@@ -1533,7 +1545,7 @@ int fail(gi_ctx* c, int code, const std::string& msg)
 static int install_pleaf_rank(gi_ctx* c)
 {
     Scene& S = c->S;
-    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0;
+    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0; S.pdescent = nullptr;
     if (S.n_pnode <= 0) return GI_OK;
     if (c->d_pleaf_rank.n < (size_t)S.n_pnode) { HIP_TRY(c, c->d_pleaf_rank.alloc((size_t)S.n_pnode)); HIP_TRY(c, c->d_prank_leaf.alloc((size_t)S.n_pnode)); }
     if (!c->d_n_pleaf.p) HIP_TRY(c, c->d_n_pleaf.alloc(1));
@@ -1543,6 +1555,17 @@ static int install_pleaf_rank(gi_ctx* c)
     HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_pleaf.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     S.pleaf_rank = c->d_pleaf_rank.p; S.prank_leaf = c->d_prank_leaf.p; S.n_pleaf = n;
+    // the split records of the descent and the map's own box (gather_find_leaf_fast); the one-record-per-level layout only (children from the parent's planes)
+    if (c->fast_descent && S.pn_planes) {
+        if (c->d_pdescent.n < (size_t)S.n_pnode) HIP_TRY(c, c->d_pdescent.alloc((size_t)S.n_pnode));
+        hipLaunchKernelGGL(k_pdescent, dim3((unsigned)((S.n_pnode + 255) / 256)), dim3(256), 0, c->stream, S.pnodes, S.n_pnode, c->d_pdescent.p);
+        HIP_TRY(c, hipGetLastError());
+        PNode root;
+        HIP_TRY(c, hipMemcpyAsync(&root, S.pnodes, sizeof(PNode), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 3; k++) { S.pmap_bmin[k] = root.bmin[k]; S.pmap_bmax[k] = root.bmax[k]; }
+        S.pdescent = c->d_pdescent.p;
+    }
     return GI_OK;
 }
 
@@ -1578,6 +1601,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
     if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
     if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
+    if (const char* e = getenv("GI_FAST_DESCENT")) c->fast_descent = atoi(e) != 0;
     if (const char* e = getenv("GI_ENTITY_BOXES")) c->entity_boxes = atoi(e) != 0;
     if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
@@ -2161,6 +2185,7 @@ int gi_set_wide_nodes(gi_ctx* c, int enable)
     c->S.wnodes = (c->wide_enabled && c->S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
     c->S.cboxes = (c->cull_enabled && c->S.wnodes && c->d_cboxes.n > 1) ? c->d_cboxes.p : nullptr;
     c->S.pn_planes = (c->wide_enabled && c->pn_planes_ok) ? 1 : 0;   // the photon octree's counterpart (gather_find_leaf)
+    c->S.pdescent = (c->S.pn_planes && c->fast_descent && c->S.n_pnode > 0 && c->d_pdescent.n >= (size_t)c->S.n_pnode) ? c->d_pdescent.p : nullptr;
     return (c->S.wnodes ? 1 : 0) | (c->S.pn_planes ? 2 : 0);
 }
 
