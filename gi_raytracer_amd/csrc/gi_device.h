@@ -127,6 +127,7 @@ struct Scene {
     const int32_t* leaf_refs;
     const LeafTri* leaf_tris; // [n_refs], parallel to leaf_refs
     const double* leaf_boxes; // [n_refs][6] every reference's own box (min xyz, max xyz, widened): a ray that misses it cannot hit the entity; null = not used
+    const double* trace_boxes;// [n_refs][6] the same for the closest-hit walk: where the rules of trace_wide_step allow it, the part of the entity inside its leaf; null with leaf_boxes
     const TriGeom* tris;
     const TriShade* shade;
     const TriUV* tri_uv;      // [n_tri], only when n_tex > 0
@@ -156,6 +157,7 @@ struct Scene {
     double ambient[3];
     double root_bmin[3], root_bmax[3];   // box of octree node 0 (kernel argument: no memory round trip before a walk starts)
     double pmap_bmin[3], pmap_bmax[3];   // box of the photon map's root (gather_find_leaf_fast)
+    double cut_margin;        // >= 0: a closest-hit walk looks no further than its best hit plus this (trace_wide_step); < 0: it walks on as the reference does
 };
 
 struct Counters { unsigned long long v_trace, v_shadow, tri, shaded, pcand, traces, shadows, gathers; };
@@ -671,12 +673,12 @@ GI_HD bool entity_box_missed(const double* b, const Ray& r, double tc)
     return !(tf >= tn);
 }
 // the references [first, first + cnt) of a leaf (cnt <= 32) whose boxes the ray touches, as a bit mask; all of them without the table
-GI_HD uint32_t entity_survivors(const Scene& S, int32_t first, int32_t cnt, const Ray& r, double tc)
+GI_HD uint32_t entity_survivors(const double* boxes, int32_t first, int32_t cnt, const Ray& r, double tc)
 {
     uint32_t m = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
-    if (!S.leaf_boxes) return m;
+    if (!boxes) return m;
     for (int32_t j = 0; j < cnt; j++)
-        if (entity_box_missed(S.leaf_boxes + (size_t)(first + j) * 6, r, tc)) m &= ~(1u << j);
+        if (entity_box_missed(boxes + (size_t)(first + j) * 6, r, tc)) m &= ~(1u << j);
     return m;
 }
 // bit k of the result: the k-th child in this ray's front-to-back order (slot k ^ a) exists and its box is hit in (tmin0, tmax0)
@@ -836,6 +838,7 @@ struct TraceWalk {
     WRay wr;
     WWalk k;
     bool intersected;
+    bool tie, plain;   // tie: two entities at the very same distance were met; plain: this walk asks every entity the reference asks (see trace_wide_step)
     double best_d2;
     double cu, cv;   // the reference's `glm::dvec2 uv` of trace(): written by every successful intersect of a smooth triangle or sphere
 };
@@ -844,6 +847,26 @@ GI_HD bool trace_wide_begin(const Scene& S, const WN& W, const Ray& ray, TraceWa
 {
     t.wr = wray_make(ray);
     t.intersected = false;
+    // a ray that runs exactly along an axis plane may lie IN the face two leaves share and touch both all the way: leaves then do not follow
+    // each other along it, which the short cuts of trace_wide_step take for granted -- such a ray walks the plain way
+    t.tie = false; t.plain = !(fabs(ray.inv.x) < INFINITY && fabs(ray.inv.y) < INFINITY && fabs(ray.inv.z) < INFINITY);
+    t.best_d2 = 0; t.cu = 0; t.cv = 0;
+    return wwalk_begin(S, W, t.k, ray, t.wr, 0.0, INFINITY);
+}
+// Two short cuts of the closest-hit walk, both leaving the hit RayTracer::trace returns (include/raytracer.h:446-472) as it is:
+//  * the reference ends a walk only when the best hit lies inside the leaf it was found from; a hit found from an earlier leaf (a large
+//    entity sticks out of it) lets it walk on to the end of the ray, testing entities that cannot win (it takes a hit only when it is
+//    strictly nearer).  Here nothing that begins more than `cut_margin` behind the best hit is looked at: nodes, leaves, entities.
+//  * trace_boxes: for an opaque entity of a scene without textures, the box of the part of it INSIDE the leaf (widened): a hit outside the
+//    leaf is found again from the leaf it lies in, with the same arithmetic, so asking for it here only brings the answer forward.
+// Both widen by 1e-5 of the scene, a hundred times what the float arithmetic of the tree builder can misplace an entity by.  What the second
+// could change is WHICH of two entities at exactly the same distance is met first; such a walk (t.tie) is made again the plain way.
+template <class WN>
+GI_HD bool trace_wide_over(const Scene& S, const WN& W, const Ray& ray, TraceWalk& t)   // the walk ended: true when it has to be made again
+{
+    if (!t.tie || t.plain) return false;
+    t.wr.tc = INFINITY;
+    t.intersected = false; t.tie = false; t.plain = true;
     t.best_d2 = 0; t.cu = 0; t.cv = 0;
     return wwalk_begin(S, W, t.k, ray, t.wr, 0.0, INFINITY);
 }
@@ -852,10 +875,13 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
 {
     int32_t lnode = 0, first = 0, cnt = 0;
     int lslot = 0;
-    if (!wwalk_next_leaf(W, t.k, ray, t.wr, 0.0, INFINITY, lnode, lslot, first, cnt)) return false;
+    bool term = false;
+    if (wwalk_next_leaf(W, t.k, ray, t.wr, 0.0, t.wr.tc, lnode, lslot, first, cnt)) {
     GI_DIV(W, 2);
     W.tick_leaf();
-    bool term = false;
+    // an entity beyond the best hit cannot replace it (strict <): without textures its test changes nothing; with them a successful intersect
+    // leaves its uv behind for the alpha look-up of the next flat entity (t.cu / t.cv), so every entity of a visited leaf is still asked
+#define GI_TCE ((FEAT & GI_FEAT_TEX) ? INFINITY : t.wr.tc)
     auto test = [&](const LeafTri& g) {
         const int32_t ti = g.tri;
         double u, v;
@@ -869,11 +895,13 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
             if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return;
         }
         double d2 = len2(hp - ray.o);
+        if (t.intersected && d2 == t.best_d2 && ti != best.tri) t.tie = true;
         if (!t.intersected || d2 < t.best_d2) {
             best.pos = hp; best.u = u; best.v = v; best.tri = ti; best.mf = g.matflags;
             if (FEAT & GI_FEAT_TEX) { best.tu = t.cu; best.tv = t.cv; }
             t.best_d2 = d2;
             t.intersected = true;
+            if (S.cut_margin >= 0 && !t.plain) t.wr.tc = sqrt(d2) + S.cut_margin;   // nothing that begins behind this can be nearer
             double lmin[3], lmax[3];
             W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
             if (box_contains(lmin, lmax, hp)) term = true;
@@ -886,8 +914,8 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
             // every lane holds its own ray against the same entity: the record is only fetched when some lane's ray touches the entity's box
             W.tick_ebox((uint32_t)cnt_u);
             for (int32_t j = 0; j < cnt_u; j++) {
-                const Box6 bx = leaf_box_scalar(S.leaf_boxes + (size_t)(first_u + j) * 6);
-                const bool touch = !entity_box_missed(bx.b, ray, INFINITY);
+                const Box6 bx = leaf_box_scalar(S.trace_boxes + (size_t)(first_u + j) * 6);
+                const bool touch = t.plain || !entity_box_missed(bx.b, ray, GI_TCE);
                 if (__ballot(touch) == 0ull) continue;
                 const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
                 GI_DIV(W, 4);
@@ -899,7 +927,8 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
 #endif
     if (S.leaf_boxes && cnt <= 32) {
         // the references whose boxes the ray touches, in leaf order (one or two per leaf: a single record in flight)
-        uint32_t m = entity_survivors(S, first, cnt, ray, INFINITY);
+        uint32_t m = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+        if (!t.plain) m = entity_survivors(S.trace_boxes, first, cnt, ray, GI_TCE);
         W.tick_ebox((uint32_t)cnt);
         while (m) {
             const int j = __builtin_ctz(m);
@@ -915,7 +944,10 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
             test(g0);
             if (j + 1 < cnt) { GI_DIV(W, 6); test(g1); }
         }
-    return !term;
+#undef GI_TCE
+    if (!term) return true;
+    }
+    return trace_wide_over(S, W, ray, t);
 }
 template <int FEAT, class WN>
 GI_HD bool trace_wide(const Scene& S, const WN& W, const Ray& ray, const Rng& rng, uint32_t alpha_purpose, HitRec& best)
@@ -983,7 +1015,7 @@ GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, doub
     }
 #endif
     if (S.leaf_boxes && cnt <= 32) {
-        uint32_t m = entity_survivors(S, first, cnt, ray, sqrt(mt) * (1.0 + 1e-9));   // a blocker lies before the light: 0 < |hit - o|^2 < mt
+        uint32_t m = entity_survivors(S.leaf_boxes, first, cnt, ray, sqrt(mt) * (1.0 + 1e-9));   // a blocker lies before the light: 0 < |hit - o|^2 < mt
         W.tick_ebox((uint32_t)cnt);
         while (m) {
             const int j = __builtin_ctz(m);

@@ -1461,7 +1461,11 @@ struct gi_ctx {
     DevBuf<int32_t> d_refs;
     DevBuf<LeafTri> d_leaf_tris;
     DevBuf<double> d_leaf_boxes;          // every leaf reference's own box (gi_device.h: entity_survivors)
+    DevBuf<double> d_trace_boxes;         // the closest-hit walk's boxes (gi_device.h: trace_wide_step)
+    double cut_margin = -1;               // of the scene last uploaded
     bool entity_boxes = true;             // GI_ENTITY_BOXES=0: every entity of a leaf is tested, as the reference does
+    bool clip_boxes = true;               // GI_CLIP_BOXES=0: the closest-hit walk uses the entities' whole boxes
+    bool walk_cut = true;                 // GI_WALK_CUT=0: the closest-hit walk goes on behind its best hit, as the reference does
     DevBuf<TriGeom> d_tris;
     DevBuf<TriShade> d_shade;
     DevBuf<Mat> d_mats;
@@ -1603,6 +1607,8 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
     if (const char* e = getenv("GI_FAST_DESCENT")) c->fast_descent = atoi(e) != 0;
     if (const char* e = getenv("GI_ENTITY_BOXES")) c->entity_boxes = atoi(e) != 0;
+    if (const char* e = getenv("GI_CLIP_BOXES")) c->clip_boxes = atoi(e) != 0;
+    if (const char* e = getenv("GI_WALK_CUT")) c->walk_cut = atoi(e) != 0;
     if (const char* e = getenv("GI_REFILL_MIN")) c->refill_min = (uint32_t)std::min(64, std::max(1, atoi(e)));
     if (const char* e = getenv("GI_FINISH_THRESHOLD")) c->finish_threshold = (uint32_t)strtoul(e, nullptr, 0);   // tuning knobs
     if (const char* e = getenv("GI_FINISH_PLAN")) {   // "lanes:vertices,lanes:vertices,..."
@@ -1641,6 +1647,16 @@ int gi_set_stream(gi_ctx* c, void* s)
     return GI_OK;
 }
 
+// Which of the walks' short cuts are on (all of them leave every result as it is: DESIGN.md section 4): entity boxes; for the closest-hit walk
+// the boxes cut to the leaves, and no look behind the best hit.  gi_set_entity_boxes(ctx, 0) turns all three off: the walks then ask what the reference asks.
+static void set_walk_shortcuts(gi_ctx* c)
+{
+    Scene& S = c->S;
+    S.leaf_boxes = c->entity_boxes ? c->d_leaf_boxes.p : nullptr;
+    S.trace_boxes = !c->entity_boxes ? nullptr : (c->clip_boxes ? c->d_trace_boxes.p : c->d_leaf_boxes.p);
+    S.cut_margin = (c->entity_boxes && c->walk_cut) ? c->cut_margin : -1.0;
+}
+
 int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
 {
     if (!c) return GI_E_INVALID;
@@ -1660,6 +1676,8 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_refs.upload(H.refs));
     HIP_TRY(c, c->d_leaf_tris.upload(H.leaf_tris));
     HIP_TRY(c, c->d_leaf_boxes.upload(H.leaf_boxes));
+    HIP_TRY(c, c->d_trace_boxes.upload(H.trace_boxes));
+    c->cut_margin = H.cut_margin;
     HIP_TRY(c, c->d_tris.upload(H.tris));
     HIP_TRY(c, c->d_shade.upload(H.shade));
     HIP_TRY(c, c->d_mats.upload(H.mats));
@@ -1669,7 +1687,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     Scene& S = c->S;
     S.tnodes = c->d_tnodes.p; S.leaf_refs = c->d_refs.p; S.leaf_tris = c->d_leaf_tris.p; S.tris = c->d_tris.p; S.shade = c->d_shade.p;
     S.mats = c->d_mats.p; S.lights = c->d_lights.p;
-    S.leaf_boxes = c->entity_boxes ? c->d_leaf_boxes.p : nullptr;
+    set_walk_shortcuts(c);
     S.n_node = H.n_node; S.n_tri = H.n_tri; S.n_light = H.n_light;
     for (int k = 0; k < 3; k++) { S.root_bmin[k] = H.tnodes[0].bmin[k]; S.root_bmax[k] = H.tnodes[0].bmax[k]; }
     S.n_wnode = (int32_t)H.wnodes.size();
@@ -2201,7 +2219,7 @@ int gi_set_entity_boxes(gi_ctx* c, int enable)
 {
     if (!c) return GI_E_INVALID;
     c->entity_boxes = enable != 0;
-    c->S.leaf_boxes = (c->entity_boxes && c->have_scene) ? c->d_leaf_boxes.p : nullptr;
+    if (c->have_scene) set_walk_shortcuts(c);
     return c->S.leaf_boxes ? 1 : 0;
 }
 

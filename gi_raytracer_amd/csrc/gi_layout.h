@@ -28,6 +28,8 @@ struct HostScene {
     std::vector<int32_t> refs;
     std::vector<LeafTri> leaf_tris;
     std::vector<double> leaf_boxes;   // [n_refs][6] the entity's own box, widened (gi_device.h: entity_box_missed), parallel to leaf_tris
+    std::vector<double> trace_boxes;  // [n_refs][6] for the closest-hit walk: the box of the part of an opaque entity inside its leaf (gi_device.h: trace_wide_step)
+    double cut_margin = -1;           // what the closest-hit walk's short cuts allow for rounding (1e-5 of the scene)
     std::vector<TriGeom> tris;
     std::vector<TriShade> shade;
     std::vector<TriUV> tri_uv;
@@ -360,8 +362,11 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
     }
     if (H.leaf_tris.empty()) H.leaf_tris.resize(1);
     {   // the entities' own boxes, leaf-reference order: what a ray has to touch before Entity::intersect can succeed
-        double extent = 0;
-        for (int ax = 0; ax < 3; ax++) extent = std::max(extent, d->node_bbox[3 + ax] - d->node_bbox[ax]);
+        double extent = 0, reach = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            extent = std::max(extent, d->node_bbox[3 + ax] - d->node_bbox[ax]);
+            reach = std::max(reach, std::max(std::fabs(d->node_bbox[ax]), std::fabs(d->node_bbox[3 + ax])));
+        }
         const double margin = 1e-7 * std::max(extent, 1e-3);     // as for the content boxes: a hit point is off its entity by ~1e-16 of its coordinates
         H.leaf_boxes.assign(std::max<size_t>(H.refs.size(), 1) * 6, 0.0);
         for (size_t r = 0; r < H.refs.size(); r++) {
@@ -375,6 +380,60 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
                     b[ax] = std::min(P[ax], std::min(P[3 + ax], P[6 + ax])) - margin;
                     b[3 + ax] = std::max(P[ax], std::max(P[3 + ax], P[6 + ax])) + margin;
                 }
+        }
+        // The closest-hit walk's boxes: the part of the entity inside the leaf that refers to it.  The tree builder decides in float arithmetic which
+        // leaves an entity overlaps (relative error 1e-7 of the coordinates), so the leaf is taken 1e-5 of the scene larger before the entity
+        // is cut to it, and the box of what is left is widened by as much again: a hit point within rounding of a leaf is never refused there.
+        // Entities with an alpha test keep their whole box (the test draws per leaf: include/raytracer.h:455), and so does everything in a
+        // scene with textures (a hit leaves its uv behind for the next entity's alpha look-up).
+        const double wide = 1e-5 * std::max(std::max(extent, reach), 1e-3);
+        H.cut_margin = wide;
+        H.trace_boxes = H.leaf_boxes;
+        const bool textured = [&] { for (int t = 0; t < d->n_tex; t++) if (d->tex_kind[t] != 0) return true; return false; }();
+        for (int n = 0; n < d->n_node && !textured; n++) {
+            bool inner = false;
+            for (int k = 0; k < 8; k++) if (d->node_child[(size_t)n * 8 + k] >= 0) inner = true;
+            if (inner) continue;
+            double lo[3], hi[3];
+            for (int ax = 0; ax < 3; ax++) { lo[ax] = d->node_bbox[(size_t)n * 6 + ax] - wide; hi[ax] = d->node_bbox[(size_t)n * 6 + 3 + ax] + wide; }
+            for (int r = d->node_ent_off[n]; r < d->node_ent_off[n + 1]; r++) {
+                const int e = H.refs[(size_t)r];
+                if (!(H.tris[(size_t)e].flags & 2u)) continue;
+                const double* P = d->tri_pos + (size_t)e * 9;
+                double* b = &H.trace_boxes[(size_t)r * 6];
+                double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+                if (d->ent_kind && d->ent_kind[e] == 1) {
+                    for (int ax = 0; ax < 3; ax++) { cmin[ax] = std::max(P[ax] - P[3], lo[ax]); cmax[ax] = std::min(P[ax] + P[3], hi[ax]); }
+                } else {
+                    // Sutherland-Hodgman: the triangle against the six planes of the (enlarged) leaf, in doubles
+                    double poly[2][10][3];
+                    int np = 3, cur = 0;
+                    for (int v = 0; v < 3; v++) for (int ax = 0; ax < 3; ax++) poly[0][v][ax] = P[v * 3 + ax];
+                    for (int pl = 0; pl < 6 && np > 0; pl++) {
+                        const int ax = pl >> 1;
+                        const bool upper = pl & 1;
+                        const double lim = upper ? hi[ax] : lo[ax];
+                        int nn = 0;
+                        for (int v = 0; v < np; v++) {
+                            const double* A = poly[cur][v];
+                            const double* B = poly[cur][(v + 1) % np];
+                            const bool ain = upper ? A[ax] <= lim : A[ax] >= lim, bin = upper ? B[ax] <= lim : B[ax] >= lim;
+                            if (ain) { for (int k = 0; k < 3; k++) poly[cur ^ 1][nn][k] = A[k]; nn++; }
+                            if (ain != bin) {
+                                const double f = (lim - A[ax]) / (B[ax] - A[ax]);
+                                for (int k = 0; k < 3; k++) poly[cur ^ 1][nn][k] = k == ax ? lim : A[k] + f * (B[k] - A[k]);
+                                nn++;
+                            }
+                        }
+                        cur ^= 1;
+                        np = nn;
+                    }
+                    for (int v = 0; v < np; v++) for (int ax = 0; ax < 3; ax++) { cmin[ax] = std::min(cmin[ax], poly[cur][v][ax]); cmax[ax] = std::max(cmax[ax], poly[cur][v][ax]); }
+                }
+                const bool empty = !(cmin[0] <= cmax[0] && cmin[1] <= cmax[1] && cmin[2] <= cmax[2]);
+                // nothing of the entity near this leaf: a point no ray of the scene reaches (entity_box_missed has no empty box)
+                for (int ax = 0; ax < 3; ax++) { b[ax] = empty ? 1e300 : std::max(b[ax], cmin[ax] - wide); b[3 + ax] = empty ? 1e300 : std::min(b[3 + ax], cmax[ax] + wide); }
+            }
         }
     }
     H.mats.resize((size_t)d->n_mat);

@@ -21,8 +21,12 @@ struct Emul {
     bool wide = true, cull = true;
     void bind()
     {
-        S.tnodes = hs.tnodes.data(); S.leaf_refs = hs.refs.data(); S.leaf_tris = hs.leaf_tris.data(); S.leaf_boxes = getenv("GI_ENTITY_BOXES") && atoi(getenv("GI_ENTITY_BOXES")) == 0 ? nullptr : hs.leaf_boxes.data(); S.tris = hs.tris.data(); S.shade = hs.shade.data();
+        S.tnodes = hs.tnodes.data(); S.leaf_refs = hs.refs.data(); S.leaf_tris = hs.leaf_tris.data(); S.tris = hs.tris.data(); S.shade = hs.shade.data();
         S.mats = hs.mats.data(); S.lights = hs.lights.data();
+        auto off = [](const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; };   // the product's knobs (gi_kernels.hip: set_walk_shortcuts)
+        S.leaf_boxes = off("GI_ENTITY_BOXES") ? nullptr : hs.leaf_boxes.data();
+        S.trace_boxes = !S.leaf_boxes ? nullptr : (off("GI_CLIP_BOXES") ? hs.leaf_boxes.data() : hs.trace_boxes.data());
+        S.cut_margin = (S.leaf_boxes && !off("GI_WALK_CUT")) ? hs.cut_margin : -1.0;
         S.n_node = hs.n_node; S.n_tri = hs.n_tri; S.n_light = hs.n_light; S.has_spheres = 1;
         if (!hs.tnodes.empty()) for (int k = 0; k < 3; k++) { S.root_bmin[k] = hs.tnodes[0].bmin[k]; S.root_bmax[k] = hs.tnodes[0].bmax[k]; }
         S.n_wnode = (int32_t)hs.wnodes.size();
