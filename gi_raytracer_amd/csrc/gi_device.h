@@ -124,6 +124,8 @@ struct Scene {
     const int32_t* wleaf_id;  // [n_wnode][8] canonical node index of a leaf child (RNG key of the alpha test)
     const float* cboxes;      // [n_wnode][8][6] content box of every child's sub-tree (all entities referenced below it), rounded outwards; null = no culling
     const uint32_t* cuse;     // [n_wnode] children (slot bits) whose content box is worth testing (clearly smaller than their octant)
+    const float* tcboxes;     // the same two tables made of trace_boxes, for the streaming closest-hit walk (k_st_trace); = cboxes / cuse where nothing is cut to its leaf
+    const uint32_t* tcuse;
     const int32_t* leaf_refs;
     const LeafTri* leaf_tris; // [n_refs], parallel to leaf_refs
     const double* leaf_boxes; // [n_refs][6] every reference's own box (min xyz, max xyz, widened): a ray that misses it cannot hit the entity; null = not used
@@ -610,14 +612,24 @@ struct GlobalNodes {
 // their parent.  BoundingBox::intersect updates tmin upwards and tmax downwards axis by axis and leaves at the first
 // tmax <= tmin (include/bbox.h:47-73); both are monotone, so it returns false exactly when the final tmax <= tmin, and
 // `t0 > tmin ? t0 : tmin` is maxNum (a NaN from 0 * inf is ignored), which is what fmax / v_max_f64 compute.
-struct WRay { int off[3]; int a; double tc; };   // per axis: 8 when the ray runs backwards along it (invDir < 0), else 0; a = direction octant;
-                                                  // tc = parameter beyond which no hit can count (content-box culling)
+struct WRay { int a; double tc; bool plain; };   // a = direction octant; tc = parameter beyond which no hit can count (content-box culling, the closest-hit walk's cut);
+                                                  // plain: a closest-hit walk that asks every entity the reference asks (trace_wide_step): no content culling either
+// 8 when the ray runs backwards along an axis (invDir < 0), else 0: the byte offset between a plane pair's near and far side in a wide record.  Read off
+// the sign bit of 1/d each time (1/d is never a zero or a NaN) -- three registers a walk does not have to hold
+GI_HD int back_off(double inv)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(((uint32_t)__double2hiint(inv) >> 31) << 3);
+#else
+    return inv < 0.0 ? 8 : 0;
+#endif
+}
 GI_HD WRay wray_make(const Ray& r)
 {
     WRay w;
-    w.off[0] = r.inv.x < 0.0 ? 8 : 0; w.off[1] = r.inv.y < 0.0 ? 8 : 0; w.off[2] = r.inv.z < 0.0 ? 8 : 0;
     w.a = (r.d.x < 0.0 ? 1 : 0) | (r.d.z < 0.0 ? 2 : 0) | (r.d.y < 0.0 ? 4 : 0);
     w.tc = INFINITY;
+    w.plain = false;
     return w;
 }
 // Content-box culling.  The reference's octree cuts space, not content: a leaf that holds a piece of the floor spans its whole octant, and
@@ -646,7 +658,7 @@ GI_HD uint32_t content_cull(const float* cboxes, const uint32_t* cuse, int32_t n
         for (int ax = 0; ax < 3; ax++) {
             // entry plane first: a NaN (origin exactly on a plane of an axis the ray does not move along: 0 * inf) is ignored by fmax / fmin,
             // which is the right answer -- the origin is inside that closed slab
-            const int back = wr.off[ax] ? 3 : 0;
+            const int back = back_off(inv[ax]) ? 3 : 0;
             tn = fmax(tn, ((double)b[ax + back] - o[ax]) * inv[ax]);
             tf = fmin(tf, ((double)b[ax + 3 - back] - o[ax]) * inv[ax]);
         }
@@ -688,7 +700,7 @@ GI_HD uint32_t wide_hits(const WNode* w, const Ray& r, const WRay& wr, double tm
     const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
     double n[3][3], f[3][3];   // [axis][low side, high side, child 7]: entry and exit parameter
     for (int ax = 0; ax < 3; ax++) {
-        const int A = ax * 48, x = wr.off[ax], y = x ^ 8;
+        const int A = ax * 48, x = back_off(inv[ax]), y = x ^ 8;
         n[ax][0] = (*reinterpret_cast<const double*>(b + A + x) - o[ax]) * inv[ax];
         f[ax][0] = (*reinterpret_cast<const double*>(b + A + y) - o[ax]) * inv[ax];
         n[ax][1] = (*reinterpret_cast<const double*>(b + A + 16 + x) - o[ax]) * inv[ax];
@@ -757,7 +769,7 @@ struct GlobalWide : NoWalkCnt {
     mutable uint32_t ds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     template <class F> GI_HDM auto with(int32_t i, F&& f) const { return f(g + i); }
-    GI_HDM uint32_t cull(int32_t node, uint32_t m, const Ray& r, const WRay& wr) const { return cboxes ? content_cull(cboxes, cuse, node, m, r, wr) : m; }
+    GI_HDM uint32_t cull(int32_t node, uint32_t m, const Ray& r, const WRay& wr) const { return (cboxes && !wr.plain) ? content_cull(cboxes, cuse, node, m, r, wr) : m; }
 };
 // walk state: the node, the children of it still to visit (bit k = k-th in order), and the same masks of its ancestors, one
 // byte per level, in a 128-bit shift register (16 levels; deeper trees keep the per-node walk)
@@ -838,7 +850,7 @@ struct TraceWalk {
     WRay wr;
     WWalk k;
     bool intersected;
-    bool tie, plain;   // tie: two entities at the very same distance were met; plain: this walk asks every entity the reference asks (see trace_wide_step)
+    bool tie;          // two entities at the very same distance were met (trace_wide_step)
     double best_d2;
     double cu, cv;   // the reference's `glm::dvec2 uv` of trace(): written by every successful intersect of a smooth triangle or sphere
 };
@@ -846,10 +858,10 @@ template <int FEAT, class WN>
 GI_HD bool trace_wide_begin(const Scene& S, const WN& W, const Ray& ray, TraceWalk& t)   // false: the ray misses the scene's box
 {
     t.wr = wray_make(ray);
-    t.intersected = false;
     // a ray that runs exactly along an axis plane may lie IN the face two leaves share and touch both all the way: leaves then do not follow
     // each other along it, which the short cuts of trace_wide_step take for granted -- such a ray walks the plain way
-    t.tie = false; t.plain = !(fabs(ray.inv.x) < INFINITY && fabs(ray.inv.y) < INFINITY && fabs(ray.inv.z) < INFINITY);
+    t.intersected = false; t.tie = false;
+    t.wr.plain = !(fabs(ray.inv.x) < INFINITY && fabs(ray.inv.y) < INFINITY && fabs(ray.inv.z) < INFINITY);
     t.best_d2 = 0; t.cu = 0; t.cv = 0;
     return wwalk_begin(S, W, t.k, ray, t.wr, 0.0, INFINITY);
 }
@@ -864,9 +876,9 @@ GI_HD bool trace_wide_begin(const Scene& S, const WN& W, const Ray& ray, TraceWa
 template <class WN>
 GI_HD bool trace_wide_over(const Scene& S, const WN& W, const Ray& ray, TraceWalk& t)   // the walk ended: true when it has to be made again
 {
-    if (!t.tie || t.plain) return false;
+    if (!t.tie || t.wr.plain || S.trace_boxes == S.leaf_boxes) return false;   // (whole boxes: the entities were met in the reference's order anyway)
     t.wr.tc = INFINITY;
-    t.intersected = false; t.tie = false; t.plain = true;
+    t.intersected = false; t.tie = false; t.wr.plain = true;
     t.best_d2 = 0; t.cu = 0; t.cv = 0;
     return wwalk_begin(S, W, t.k, ray, t.wr, 0.0, INFINITY);
 }
@@ -895,13 +907,15 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
             if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return;
         }
         double d2 = len2(hp - ray.o);
+#ifndef GI_EXP_NOTIE
         if (t.intersected && d2 == t.best_d2 && ti != best.tri) t.tie = true;
+#endif
         if (!t.intersected || d2 < t.best_d2) {
             best.pos = hp; best.u = u; best.v = v; best.tri = ti; best.mf = g.matflags;
             if (FEAT & GI_FEAT_TEX) { best.tu = t.cu; best.tv = t.cv; }
             t.best_d2 = d2;
             t.intersected = true;
-            if (S.cut_margin >= 0 && !t.plain) t.wr.tc = sqrt(d2) + S.cut_margin;   // nothing that begins behind this can be nearer
+            if (S.cut_margin >= 0 && !t.wr.plain) t.wr.tc = sqrt(d2) + S.cut_margin;   // nothing that begins behind this can be nearer
             double lmin[3], lmax[3];
             W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
             if (box_contains(lmin, lmax, hp)) term = true;
@@ -915,7 +929,7 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
             W.tick_ebox((uint32_t)cnt_u);
             for (int32_t j = 0; j < cnt_u; j++) {
                 const Box6 bx = leaf_box_scalar(S.trace_boxes + (size_t)(first_u + j) * 6);
-                const bool touch = t.plain || !entity_box_missed(bx.b, ray, GI_TCE);
+                const bool touch = t.wr.plain || !entity_box_missed(bx.b, ray, GI_TCE);
                 if (__ballot(touch) == 0ull) continue;
                 const LeafTri g = leaf_tri_scalar(S.leaf_tris + first_u + j);
                 GI_DIV(W, 4);
@@ -928,7 +942,7 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
     if (S.leaf_boxes && cnt <= 32) {
         // the references whose boxes the ray touches, in leaf order (one or two per leaf: a single record in flight)
         uint32_t m = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
-        if (!t.plain) m = entity_survivors(S.trace_boxes, first, cnt, ray, GI_TCE);
+        if (!t.wr.plain) m = entity_survivors(S.trace_boxes, first, cnt, ray, GI_TCE);
         W.tick_ebox((uint32_t)cnt);
         while (m) {
             const int j = __builtin_ctz(m);
@@ -1260,7 +1274,7 @@ GI_HD bool trace(const Scene& S, const Ray& ray, const Rng& rng, uint32_t alpha_
     best.tu = 0; best.tv = 0;
     if (S.wnodes && !c) {   // the work counters count the reference's per-node box tests: counted runs take the per-node walk
         GlobalWide W;
-        W.g = S.wnodes; W.cboxes = S.cboxes; W.cuse = S.cuse;
+        W.g = S.wnodes; W.cboxes = S.tcboxes; W.cuse = S.tcuse;   // a closest-hit walk and nothing else: its own content boxes
         return S.n_tex > 0 ? trace_nodes<7>(S, W, ray, rng, alpha_purpose, best, nullptr) : trace_nodes<3>(S, W, ray, rng, alpha_purpose, best, nullptr);
     }
     GlobalNodes N;
@@ -1745,7 +1759,7 @@ GI_HD bool stage_trace(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
 {
     if (S.wnodes && !c) {
         GlobalWide W;
-        W.g = S.wnodes; W.cboxes = S.cboxes; W.cuse = S.cuse;
+        W.g = S.wnodes; W.cboxes = S.tcboxes; W.cuse = S.tcuse;
         return S.n_tex > 0 ? stage_trace_nodes<7>(S, W, p, seed, nullptr) : stage_trace_nodes<3>(S, W, p, seed, nullptr);
     }
     GlobalNodes N;

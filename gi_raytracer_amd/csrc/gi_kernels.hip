@@ -158,7 +158,7 @@ struct LdsWideT {
     // the content boxes of a record's children: every turn of a walk reads them right after the record -- from L2 that is the longest wait of the turn
     __device__ __forceinline__ uint32_t cull(int32_t node, uint32_t m, const Ray& r, const WRay& wr) const
     {
-        if (!cboxes) return m;
+        if (!cboxes || wr.plain) return m;
         uint32_t nt = 0;
         uint32_t* const ntp = COUNT ? &nt : nullptr;
         const uint32_t res = node < n_lc ? content_cull(reinterpret_cast<const float*>(gi_dyn_lds + box_off), reinterpret_cast<const uint32_t*>(gi_dyn_lds + use_off), node, m, r, wr, ntp)
@@ -193,33 +193,35 @@ extern "C" int gi_debug_div(unsigned long long* out, int reset)
 #endif
 template <int G> struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; static constexpr int kGroup = G; };   // the same records, one ray per group of G lanes (gi_device.h: trace_wide_coop)
 template <bool COUNT = false>
-__device__ __forceinline__ LdsWideT<COUNT> stage_wide_in_lds(const Scene& S, bool with_boxes = false, int boxes_cap = GI_LDS_WNODES_BIG)
+__device__ __forceinline__ LdsWideT<COUNT> stage_wide_in_lds(const Scene& S, bool with_boxes = false, int boxes_cap = GI_LDS_WNODES_BIG, bool trace_tables = false)
 {
     LdsWideT<COUNT> N;
     N.g = S.wnodes;
-    N.cboxes = S.cboxes; N.cuse = S.cuse;
+    N.cboxes = trace_tables ? S.tcboxes : S.cboxes; N.cuse = trace_tables ? S.tcuse : S.cuse;
     const int cap = with_boxes ? boxes_cap : GI_LDS_WNODES;
     N.box_off = GI_LDS_CBOX_OFF(cap); N.use_off = GI_LDS_CUSE_OFF(cap);
     N.n_l = S.n_wnode < cap ? S.n_wnode : cap;
     const uint4* src = reinterpret_cast<const uint4*>(S.wnodes);
     uint4* dst = reinterpret_cast<uint4*>(gi_dyn_lds);
     for (int i = threadIdx.x; i < N.n_l * (int)(sizeof(WNode) / 16); i += blockDim.x) dst[i] = src[i];
-    if (with_boxes && S.cboxes) {
+    if (with_boxes && N.cboxes) {
         N.n_lc = N.n_l;
-        const uint4* bsrc = reinterpret_cast<const uint4*>(S.cboxes);
+        const uint4* bsrc = reinterpret_cast<const uint4*>(N.cboxes);
         uint4* bdst = reinterpret_cast<uint4*>(gi_dyn_lds + N.box_off);
         for (int i = threadIdx.x; i < N.n_lc * 12; i += blockDim.x) bdst[i] = bsrc[i];   // 8 children x 6 floats = 12 x 16 bytes per record
         uint32_t* udst = reinterpret_cast<uint32_t*>(gi_dyn_lds + N.use_off);
-        for (int i = threadIdx.x; i < N.n_lc; i += blockDim.x) udst[i] = S.cuse[i];
+        for (int i = threadIdx.x; i < N.n_lc; i += blockDim.x) udst[i] = N.cuse[i];
     }
     __syncthreads();
     return N;
 }
 template <int WIDE, bool COUNT = false> struct LdsSrc;
 template <bool COUNT> struct LdsSrc<0, COUNT> { typedef LdsNodes type; static __device__ __forceinline__ LdsNodes stage(const Scene& S) { return stage_nodes_in_lds(S); }
-                         static __device__ __forceinline__ LdsNodes stage_with_boxes(const Scene& S) { return stage_nodes_in_lds(S); } };
+                         static __device__ __forceinline__ LdsNodes stage_with_boxes(const Scene& S) { return stage_nodes_in_lds(S); }
+                         static __device__ __forceinline__ LdsNodes stage_for_trace(const Scene& S) { return stage_nodes_in_lds(S); } };
 template <bool COUNT> struct LdsSrc<1, COUNT> { typedef LdsWideT<COUNT> type; static __device__ __forceinline__ type stage(const Scene& S) { return stage_wide_in_lds<COUNT>(S); }
-                         static __device__ __forceinline__ type stage_with_boxes(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true); } };
+                         static __device__ __forceinline__ type stage_with_boxes(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true); }
+                         static __device__ __forceinline__ type stage_for_trace(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true, GI_LDS_WNODES_BIG, true); } };   // the closest-hit walk's own content boxes
 // what the streaming kernels executed in one frame (gi_get_stream_counters): per-lane WalkCnt sums of k_st_trace and k_st_shadow, the rays handed
 // to each, the gather's queries and the candidates they scanned
 struct StreamCounters { unsigned long long trace[7], trace_rays, shadow[7], shadow_rays, gather_queries, gather_cand; };
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
     static_assert(sizeof(WNode) == 224 && GI_LDS_WIDE_BOXES_BYTES <= 160 * 1024, "LDS layout of the wide trace / shadow kernels");
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + GI_LDS_BIG_CNT_OFF);
     if (WIDE != 0 && threadIdx.x == 0) *s_next = 0u;
-    const typename LdsSrc<WIDE, COUNT>::type N = LdsSrc<WIDE, COUNT>::stage_with_boxes(S);   // ends with a barrier
+    const typename LdsSrc<WIDE, COUNT>::type N = LdsSrc<WIDE, COUNT>::stage_for_trace(S);   // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = g.n_gen + n_a + n_b;
     uint32_t n_rays = 0;   // COUNT: items this lane took
@@ -595,8 +597,20 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
         PathRec& p = pool[slot];
         if (hit) {
             if (gen) { path_begin_lean(p, ray, stream); slot_sample[slot] = g.id_base + i; }
+            if constexpr (WIDE != 0) {
+                // the walk carries only WHICH entity it hit: hit point and barycentrics are computed again here, by the same test with the same
+                // operands -- ten registers less to hold through the walk (the kernel runs at the 128 its four waves per SIMD leave it)
+                double ru = 0, rv = 0;
+                V3 rp = v3(0, 0, 0);
+                const TriGeom& tg = S.tris[h.tri];
+                const uint32_t mf = ((uint32_t)tg.mat << 3) | tg.flags;      // = LeafTri::matflags of every reference to it
+                ent_hit<FEAT>(tg, mf, ray, ru, rv, rp);
+                p.hpos[0] = rp.x; p.hpos[1] = rp.y; p.hpos[2] = rp.z;
+                p.hu = ru; p.hv = rv; p.htri = h.tri; p.pad = mf;
+            } else {
             p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
             p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.pad = h.mf;
+            }
             if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
         } else if (depth <= GI_MAX_DEPTH) {
             // the path ends here with a miss: L += T * ambient (stage_trace_nodes), on the per-sample radiance buffer where the path's L lives.
@@ -623,7 +637,6 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
         uint32_t item = 0, slot = 0, stream = 0;
         int32_t depth = 0;
         Ray ray = make_ray_exact(v3(0, 0, 0), v3(1, 0, 0));
-        Rng rng = rng_make(seed, 0);
         TraceWalk t;
         t.intersected = false;
         HitRec h;
@@ -656,8 +669,6 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                             item = i;
                             if constexpr (COUNT) n_rays++;
                             fetch(i, slot, ray, stream, depth);
-                            rng = rng_make(seed, stream);
-                            rng.depth = (uint32_t)depth;
                             t.intersected = false;
                             pend = true;          // over already (past MAX_DEPTH radiance() returns 0; a ray that misses the scene's box) unless the walk starts
                             if (depth <= GI_MAX_DEPTH && trace_wide_begin<FEAT>(S, N, ray, t)) { walking = true; pend = false; }
@@ -666,7 +677,11 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                 }
                 if (__ballot(walking || pend) == 0ull) break;
             }
-            if (walking && !trace_wide_step<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, t, h)) { walking = false; pend = true; }
+            if (walking) {
+                Rng rng = rng_make(seed, stream);      // only an entity with an alpha test draws: built where it is used, not held through the walk
+                rng.depth = (uint32_t)depth;
+                if (!trace_wide_step<FEAT>(S, N, ray, rng, P_TRACE_ALPHA, t, h)) { walking = false; pend = true; }
+            }
         }
     } else {
         for (uint32_t i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n_in; i0 += gridDim.x * blockDim.x) {
@@ -1462,7 +1477,10 @@ struct gi_ctx {
     DevBuf<LeafTri> d_leaf_tris;
     DevBuf<double> d_leaf_boxes;          // every leaf reference's own box (gi_device.h: entity_survivors)
     DevBuf<double> d_trace_boxes;         // the closest-hit walk's boxes (gi_device.h: trace_wide_step)
+    DevBuf<float> d_tcboxes;              // and the content boxes made of them
+    DevBuf<uint32_t> d_tcuse;
     double cut_margin = -1;               // of the scene last uploaded
+    bool scene_clipped = false;           // its trace boxes differ from the whole ones
     bool entity_boxes = true;             // GI_ENTITY_BOXES=0: every entity of a leaf is tested, as the reference does
     bool clip_boxes = true;               // GI_CLIP_BOXES=0: the closest-hit walk uses the entities' whole boxes
     bool walk_cut = true;                 // GI_WALK_CUT=0: the closest-hit walk goes on behind its best hit, as the reference does
@@ -1653,8 +1671,11 @@ static void set_walk_shortcuts(gi_ctx* c)
 {
     Scene& S = c->S;
     S.leaf_boxes = c->entity_boxes ? c->d_leaf_boxes.p : nullptr;
-    S.trace_boxes = !c->entity_boxes ? nullptr : (c->clip_boxes ? c->d_trace_boxes.p : c->d_leaf_boxes.p);
+    S.trace_boxes = !c->entity_boxes ? nullptr : ((c->clip_boxes && c->scene_clipped) ? c->d_trace_boxes.p : c->d_leaf_boxes.p);
     S.cut_margin = (c->entity_boxes && c->walk_cut) ? c->cut_margin : -1.0;
+    const bool cut_to_leaves = S.trace_boxes == c->d_trace_boxes.p && S.cboxes && c->d_tcboxes.n == c->d_cboxes.n;
+    S.tcboxes = cut_to_leaves ? c->d_tcboxes.p : S.cboxes;
+    S.tcuse = cut_to_leaves ? c->d_tcuse.p : S.cuse;
 }
 
 int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
@@ -1677,7 +1698,10 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_leaf_tris.upload(H.leaf_tris));
     HIP_TRY(c, c->d_leaf_boxes.upload(H.leaf_boxes));
     HIP_TRY(c, c->d_trace_boxes.upload(H.trace_boxes));
+    HIP_TRY(c, c->d_tcboxes.upload(H.tcboxes));
+    HIP_TRY(c, c->d_tcuse.upload(H.tcuse));
     c->cut_margin = H.cut_margin;
+    c->scene_clipped = H.clipped;
     HIP_TRY(c, c->d_tris.upload(H.tris));
     HIP_TRY(c, c->d_shade.upload(H.shade));
     HIP_TRY(c, c->d_mats.upload(H.mats));
@@ -1695,6 +1719,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     S.wleaf_id = c->d_wleaf_id.p;
     S.cboxes = (c->cull_enabled && S.wnodes && !H.cboxes.empty()) ? c->d_cboxes.p : nullptr;
     S.cuse = c->d_cuse.p;
+    set_walk_shortcuts(c);
     S.tri_uv = c->d_tri_uv.p; S.texs = c->d_texs.p; S.tex_pixels = c->d_tex_pixels.p; S.tex_lut = c->d_tex_lut.p; S.n_tex = H.n_tex();
     S.has_spheres = 0;
     S.fogs = c->d_fogs.p; S.fog_grid = c->d_fog_grid.p; S.n_fog = H.n_fog();
@@ -2202,6 +2227,7 @@ int gi_set_wide_nodes(gi_ctx* c, int enable)
     c->wide_enabled = enable != 0;
     c->S.wnodes = (c->wide_enabled && c->S.n_wnode > 0) ? c->d_wnodes.p : nullptr;
     c->S.cboxes = (c->cull_enabled && c->S.wnodes && c->d_cboxes.n > 1) ? c->d_cboxes.p : nullptr;
+    set_walk_shortcuts(c);
     c->S.pn_planes = (c->wide_enabled && c->pn_planes_ok) ? 1 : 0;   // the photon octree's counterpart (gather_find_leaf)
     c->S.pdescent = (c->S.pn_planes && c->fast_descent && c->S.n_pnode > 0 && c->d_pdescent.n >= (size_t)c->S.n_pnode) ? c->d_pdescent.p : nullptr;
     return (c->S.wnodes ? 1 : 0) | (c->S.pn_planes ? 2 : 0);
@@ -2212,6 +2238,7 @@ int gi_set_content_culling(gi_ctx* c, int enable)
     if (!c) return GI_E_INVALID;
     c->cull_enabled = enable != 0;
     c->S.cboxes = (c->cull_enabled && c->S.wnodes && c->d_cboxes.n > 1) ? c->d_cboxes.p : nullptr;
+    set_walk_shortcuts(c);
     return c->S.cboxes ? 1 : 0;
 }
 

@@ -30,6 +30,10 @@ struct HostScene {
     std::vector<double> leaf_boxes;   // [n_refs][6] the entity's own box, widened (gi_device.h: entity_box_missed), parallel to leaf_tris
     std::vector<double> trace_boxes;  // [n_refs][6] for the closest-hit walk: the box of the part of an opaque entity inside its leaf (gi_device.h: trace_wide_step)
     double cut_margin = -1;           // what the closest-hit walk's short cuts allow for rounding (1e-5 of the scene)
+    bool clipped = false;             // trace_boxes differs from leaf_boxes
+    std::vector<float> tcboxes;       // content boxes made of the trace boxes: what the closest-hit walk culls by (like cboxes; empty when !clipped)
+    std::vector<uint32_t> tcuse;
+    std::vector<int32_t> worder;      // canonical node of every wide record
     std::vector<TriGeom> tris;
     std::vector<TriShade> shade;
     std::vector<TriUV> tri_uv;
@@ -173,6 +177,62 @@ inline void link_octant(const gi_scene_desc* d, int a, int node, int32_t skip_to
     for (int i = 0; i < nk; i++) link_octant(d, a, kids[i], i + 1 < nk ? rec_of[kids[i + 1]] : skip_to, rec_of, out);
 }
 
+// Content boxes: for every child of every wide record the union of the boxes of all entities referenced in its sub-tree, rounded outwards to
+// float, and (cuse) which children's boxes are clearly smaller than their octants.  ref_boxes = null: the entities' whole boxes, widened here by
+// 1e-7 of the scene; else one (already widened) box per leaf reference -- an entry with b[0] = 1e300 stands for "nothing of it near the leaf".
+inline void layout_cboxes(const gi_scene_desc* d, const HostScene& H, const double* ref_boxes, std::vector<float>& cboxes, std::vector<uint32_t>& cuse)
+{
+    const int N = d->n_node;
+    const std::vector<int32_t>& order = H.worder;
+    std::vector<double> cb((size_t)N * 6);
+    for (int n = N - 1; n >= 0; n--) {      // children come later in pre-order
+        double* b = &cb[(size_t)n * 6];
+        b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY;
+        for (int r = d->node_ent_off[n]; r < d->node_ent_off[n + 1]; r++) {
+            if (ref_boxes) {
+                const double* q = ref_boxes + (size_t)r * 6;
+                if (q[0] == 1e300) continue;
+                for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], q[ax]); b[3 + ax] = std::max(b[3 + ax], q[3 + ax]); }
+                continue;
+            }
+            const int e = d->node_ent_idx[r];
+            const double* P = d->tri_pos + (size_t)e * 9;
+            if (d->ent_kind && d->ent_kind[e] == 1) {          // sphere: centre P[0..2], radius P[3]
+                for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], P[ax] - P[3]); b[3 + ax] = std::max(b[3 + ax], P[ax] + P[3]); }
+            } else
+                for (int v = 0; v < 3; v++) for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], P[v * 3 + ax]); b[3 + ax] = std::max(b[3 + ax], P[v * 3 + ax]); }
+        }
+        for (int k = 0; k < 8; k++) {
+            const int ch = d->node_child[(size_t)n * 8 + k];
+            if (ch < 0) continue;
+            for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], cb[(size_t)ch * 6 + ax]); b[3 + ax] = std::max(b[3 + ax], cb[(size_t)ch * 6 + 3 + ax]); }
+        }
+    }
+    double extent = 0;
+    for (int ax = 0; ax < 3; ax++) extent = std::max(extent, d->node_bbox[3 + ax] - d->node_bbox[ax]);
+    const double margin = ref_boxes ? 0.0 : 1e-7 * std::max(extent, 1e-3);     // a hit point is off its entity by ~1e-16 of its coordinates: eight orders of slack
+    cboxes.assign(order.size() * 48, 0.f);
+    cuse.assign(order.size(), 0u);
+    for (size_t r = 0; r < order.size(); r++) {
+        const int n = order[r];
+        for (int c = 0; c < 8; c++) {
+            const int ch = d->node_child[(size_t)n * 8 + c];
+            if (ch < 0 || !(H.wnodes[r].exists & (1u << c))) continue;
+            const double* b = &cb[(size_t)ch * 6];
+            float* out = &cboxes[(r * 8 + (size_t)c) * 6];
+            double share = 1.0;                                // how much of the octant the content (clipped to it) fills
+            for (int ax = 0; ax < 3; ax++) {
+                // (a sub-tree none of whose entities comes near its leaves: an empty box, which no ray touches)
+                out[ax] = b[ax] > b[3 + ax] ? INFINITY : std::nextafterf((float)(b[ax] - margin), -INFINITY);
+                out[3 + ax] = b[ax] > b[3 + ax] ? -INFINITY : std::nextafterf((float)(b[3 + ax] + margin), INFINITY);
+                const double olo = d->node_bbox[(size_t)ch * 6 + ax], ohi = d->node_bbox[(size_t)ch * 6 + 3 + ax];
+                const double len = std::min((double)out[3 + ax], ohi) - std::max((double)out[ax], olo);
+                share *= ohi > olo ? std::max(0.0, std::min(1.0, len / (ohi - olo))) : 1.0;
+            }
+            if (share < 0.6) cuse[r] |= 1u << c;             // the extra test is only made where it can reject something
+        }
+    }
+}
 // Wide records (gi_device.h: WNode) for the inner nodes, breadth first.  Every existing child's box must be, bit for bit, the
 // octant Octree::Node::partition gives it (include/octree.cpp:318-328): low side [min, mid], high side [lo2, hi2], child 7
 // [mid, max], with one value of mid / lo2 / hi2 per axis and node.  Returns false (and leaves H.wnodes empty) for any other tree.
@@ -240,50 +300,10 @@ inline bool layout_wide(const gi_scene_desc* d, HostScene& H)
             }
         }
     }
-    // ---- content boxes: for every node the union of the boxes of all entities referenced in its sub-tree (children come later in pre-order)
-    std::vector<double> cb((size_t)N * 6);
-    for (int n = N - 1; n >= 0; n--) {
-        double* b = &cb[(size_t)n * 6];
-        b[0] = b[1] = b[2] = INFINITY; b[3] = b[4] = b[5] = -INFINITY;
-        for (int r = d->node_ent_off[n]; r < d->node_ent_off[n + 1]; r++) {
-            const int e = d->node_ent_idx[r];
-            const double* P = d->tri_pos + (size_t)e * 9;
-            if (d->ent_kind && d->ent_kind[e] == 1) {          // sphere: centre P[0..2], radius P[3]
-                for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], P[ax] - P[3]); b[3 + ax] = std::max(b[3 + ax], P[ax] + P[3]); }
-            } else
-                for (int v = 0; v < 3; v++) for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], P[v * 3 + ax]); b[3 + ax] = std::max(b[3 + ax], P[v * 3 + ax]); }
-        }
-        for (int k = 0; k < 8; k++) {
-            const int ch = d->node_child[(size_t)n * 8 + k];
-            if (ch < 0) continue;
-            for (int ax = 0; ax < 3; ax++) { b[ax] = std::min(b[ax], cb[(size_t)ch * 6 + ax]); b[3 + ax] = std::max(b[3 + ax], cb[(size_t)ch * 6 + 3 + ax]); }
-        }
-    }
-    double extent = 0;
-    for (int ax = 0; ax < 3; ax++) extent = std::max(extent, d->node_bbox[3 + ax] - d->node_bbox[ax]);
-    const double margin = 1e-7 * std::max(extent, 1e-3);     // a hit point is off its entity by ~1e-16 of its coordinates: eight orders of slack
-    H.cboxes.assign(order.size() * 48, 0.f);
-    H.cuse.assign(order.size(), 0u);
-    for (size_t r = 0; r < order.size(); r++) {
-        const int n = order[r];
-        for (int c = 0; c < 8; c++) {
-            const int ch = d->node_child[(size_t)n * 8 + c];
-            if (ch < 0 || !(W[r].exists & (1u << c))) continue;
-            const double* b = &cb[(size_t)ch * 6];
-            float* out = &H.cboxes[(r * 8 + (size_t)c) * 6];
-            double share = 1.0;                                // how much of the octant the content (clipped to it) fills
-            for (int ax = 0; ax < 3; ax++) {
-                out[ax] = std::nextafterf((float)(b[ax] - margin), -INFINITY);
-                out[3 + ax] = std::nextafterf((float)(b[3 + ax] + margin), INFINITY);
-                const double olo = d->node_bbox[(size_t)ch * 6 + ax], ohi = d->node_bbox[(size_t)ch * 6 + 3 + ax];
-                const double len = std::min((double)out[3 + ax], ohi) - std::max((double)out[ax], olo);
-                share *= ohi > olo ? std::max(0.0, std::min(1.0, len / (ohi - olo))) : 1.0;
-            }
-            if (share < 0.6) H.cuse[r] |= 1u << c;             // the extra test is only made where it can reject something
-        }
-    }
+    H.worder.assign(order.begin(), order.end());
     H.wnodes.swap(W);
     H.wleaf_id.swap(L);
+    layout_cboxes(d, H, nullptr, H.cboxes, H.cuse);
     return true;
 }
 
@@ -389,6 +409,7 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         const double wide = 1e-5 * std::max(std::max(extent, reach), 1e-3);
         H.cut_margin = wide;
         H.trace_boxes = H.leaf_boxes;
+        H.clipped = false;
         const bool textured = [&] { for (int t = 0; t < d->n_tex; t++) if (d->tex_kind[t] != 0) return true; return false; }();
         for (int n = 0; n < d->n_node && !textured; n++) {
             bool inner = false;
@@ -401,6 +422,7 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
                 if (!(H.tris[(size_t)e].flags & 2u)) continue;
                 const double* P = d->tri_pos + (size_t)e * 9;
                 double* b = &H.trace_boxes[(size_t)r * 6];
+                H.clipped = true;
                 double cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
                 if (d->ent_kind && d->ent_kind[e] == 1) {
                     for (int ax = 0; ax < 3; ax++) { cmin[ax] = std::max(P[ax] - P[3], lo[ax]); cmax[ax] = std::min(P[ax] + P[3], hi[ax]); }
@@ -435,6 +457,8 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
                 for (int ax = 0; ax < 3; ax++) { b[ax] = empty ? 1e300 : std::max(b[ax], cmin[ax] - wide); b[3 + ax] = empty ? 1e300 : std::min(b[3 + ax], cmax[ax] + wide); }
             }
         }
+        H.tcboxes.clear(); H.tcuse.clear();
+        if (H.clipped && !H.wnodes.empty()) layout_cboxes(d, H, H.trace_boxes.data(), H.tcboxes, H.tcuse);
     }
     H.mats.resize((size_t)d->n_mat);
     for (int i = 0; i < d->n_mat; i++) {

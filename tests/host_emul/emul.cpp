@@ -25,7 +25,7 @@ struct Emul {
         S.mats = hs.mats.data(); S.lights = hs.lights.data();
         auto off = [](const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; };   // the product's knobs (gi_kernels.hip: set_walk_shortcuts)
         S.leaf_boxes = off("GI_ENTITY_BOXES") ? nullptr : hs.leaf_boxes.data();
-        S.trace_boxes = !S.leaf_boxes ? nullptr : (off("GI_CLIP_BOXES") ? hs.leaf_boxes.data() : hs.trace_boxes.data());
+        S.trace_boxes = !S.leaf_boxes ? nullptr : ((off("GI_CLIP_BOXES") || !hs.clipped) ? hs.leaf_boxes.data() : hs.trace_boxes.data());
         S.cut_margin = (S.leaf_boxes && !off("GI_WALK_CUT")) ? hs.cut_margin : -1.0;
         S.n_node = hs.n_node; S.n_tri = hs.n_tri; S.n_light = hs.n_light; S.has_spheres = 1;
         if (!hs.tnodes.empty()) for (int k = 0; k < 3; k++) { S.root_bmin[k] = hs.tnodes[0].bmin[k]; S.root_bmax[k] = hs.tnodes[0].bmax[k]; }
@@ -34,6 +34,9 @@ struct Emul {
         S.wleaf_id = hs.wleaf_id.data();
         S.cboxes = (cull && S.wnodes && hs.cboxes.size() > 1) ? hs.cboxes.data() : nullptr;
         S.cuse = hs.cuse.data();
+        const bool cut_to_leaves = S.cboxes && S.trace_boxes == hs.trace_boxes.data() && hs.tcboxes.size() == hs.cboxes.size();   // (gi_kernels.hip: set_walk_shortcuts)
+        S.tcboxes = cut_to_leaves ? hs.tcboxes.data() : S.cboxes;
+        S.tcuse = cut_to_leaves ? hs.tcuse.data() : S.cuse;
         S.tri_uv = hs.tri_uv.data(); S.texs = hs.texs.data(); S.tex_pixels = hs.tex_pixels.data(); S.tex_lut = hs.tex_lut.data(); S.n_tex = hs.n_tex();
         S.fogs = hs.fogs.data(); S.fog_grid = hs.fog_grid.data(); S.n_fog = hs.n_fog();
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];

@@ -214,6 +214,58 @@ def two_light_scene(with_glass=True):
     return s.rebuild()
 
 
+def coplanar_scene():
+    """Entities that lie in one plane and overlap (a patch on the floor of a room, a panel in its ceiling -- what a Cornell box's light is): a ray into the
+    overlap meets two entities at exactly the same distance and RayTracer::trace keeps the one it asks first (include/raytracer.h:446-472, strict <).
+    The large floor triangles reach through many leaves, the patch through few, blocks on the floor make the octree split around them."""
+    s = gi.Scene()
+    white = s.add_material(1, 1, 1, (0.8, 0.8, 0.8)); red = s.add_material(1, 1, 1, (0.8, 0.3, 0.2)); blue = s.add_material(1, 1, 1, (0.2, 0.3, 0.8))
+    quad = lambda a, b, c, d: [[a, b, c], [a, c, d]]
+    tris, mats = [], []
+    def put(q, m):
+        tris.extend(quad(*q)); mats.extend([m, m])
+    put(((-4, 0, -4), (-4, 0, 4), (4, 0, 4), (4, 0, -4)), white)                      # floor
+    put(((-4, 4, -4), (4, 4, -4), (4, 4, 4), (-4, 4, 4)), white)                      # ceiling
+    put(((-1.5, 0, -1.25), (-1.5, 0, 2.5), (2.25, 0, 2.5), (2.25, 0, -1.25)), red)    # patch in the floor's plane
+    put(((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1)), blue)                       # panel in the ceiling's plane
+    put(((-1.5, 0, -1.25), (-1.5, 0, 2.5), (2.25, 0, 2.5), (2.25, 0, -1.25)), blue)   # and the patch once more: the very same triangles
+    rs = np.random.RandomState(11)
+    for k in range(40):                                                               # small blocks standing on the floor
+        x, z = rs.uniform(-3.5, 3.3, 2)
+        w, h = rs.uniform(0.05, 0.2), rs.uniform(0.1, 0.6)
+        (x0, y0, z0), (x1, y1, z1) = (x, 0.0, z), (x + w, h, z + w)
+        for q in (((x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0)), ((x0, y0, z1), (x0, y1, z1), (x1, y1, z1), (x1, y0, z1)),
+                  ((x0, y0, z0), (x0, y1, z0), (x0, y1, z1), (x0, y0, z1)), ((x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0)),
+                  ((x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1))):
+            put(q, white)
+    s.add_triangles(np.array(tris, float), mat_idx=mats)
+    s.add_light((0, 3.5, 0), (9, 9, 9), 0.1)
+    s.set_camera((0.2, 2.2, 5.5), (0, 0.5, 0))
+    return s.rebuild()
+
+
+def check_equal_distance_hits(rt, scene, set_wide):
+    """Rays into overlapping coplanar entities: the walk with its short cuts (boxes cut to the leaves, no look behind the best hit) returns the entity
+    the plain per-node walk returns -- the one the reference meets first -- bit for bit, also where two or three entities tie."""
+    rs = np.random.RandomState(3)
+    n = 20000
+    o = np.stack([rs.uniform(-3.5, 3.5, n), rs.uniform(0.5, 3.5, n), rs.uniform(-3.5, 3.5, n)], 1)
+    tgt = np.stack([rs.uniform(-2.5, 3.0, n), np.where(rs.rand(n) < 0.7, 0.0, 4.0), rs.uniform(-2.0, 3.0, n)], 1)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    rays = np.concatenate([o, d], 1)
+    assert set_wide(True)
+    hit_w, ent_w, res_w = rt.trace(rays)
+    set_wide(False)
+    hit_n, ent_n, res_n = rt.trace(rays)
+    set_wide(True)
+    assert np.array_equal(hit_w, hit_n) and np.array_equal(ent_w, ent_n)
+    assert np.array_equal(res_w[hit_w > 0].view(np.uint64), res_n[hit_n > 0].view(np.uint64))
+    ents = set(ent_w[hit_w > 0].tolist())
+    assert ents & {0, 1} and ents & {2, 3} and len(ents) > 20         # floor, ceiling, blocks
+    return ents
+
+
 def check_gather_float_ties(rt_factory):
     """Photons whose squared distances to the query agree to float precision around rank 32: the float-key heap cannot
     separate them, the exact pass must.  40 photons on a ray from the query point, spacing 1e-9."""

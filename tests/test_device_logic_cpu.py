@@ -75,6 +75,14 @@ def test_wide_walk_equals_per_node_walk(setup):
     pc.check_wide_walk(setup[2], setup[1], setup[2].set_wide_nodes)
 
 
+def test_hits_at_equal_distance_go_to_the_entity_met_first():
+    scene = pc.coplanar_scene()
+    rt = el.EmulRayTracer().setScene(scene)
+    pc.check_equal_distance_hits(rt, scene, rt.set_wide_nodes)
+    pc.check_wide_walk(rt, scene, rt.set_wide_nodes)
+    pc.check_render(rt, scene, 48, 32, 8, 0)        # and a frame against the oracle, which asks the entities in the reference's order
+
+
 def test_content_culling_changes_nothing(setup):
     pc.check_content_culling(setup[2], setup[1], render=setup[0] in ("caustics", "spheres_opaque"))
 
