@@ -124,6 +124,9 @@ struct Scene {
     const int32_t* wleaf_id;  // [n_wnode][8] canonical node index of a leaf child (RNG key of the alpha test)
     const float* cboxes;      // [n_wnode][8][6] content box of every child's sub-tree (all entities referenced below it), rounded outwards; null = no culling
     const uint32_t* cuse;     // [n_wnode] children (slot bits) whose content box is worth testing (clearly smaller than their octant)
+    const double* shadow_boxes;   // boxes for segments that END AT A LIGHT (k_st_shadow): trace_boxes when no entity comes near a light (visible_leaf_blocks), else leaf_boxes
+    const float* scboxes;     // and the content boxes that go with them (= tcboxes / tcuse, or cboxes / cuse)
+    const uint32_t* scuse;
     const float* tcboxes;     // the same two tables made of trace_boxes, for the streaming closest-hit walk (k_st_trace); = cboxes / cuse where nothing is cut to its leaf
     const uint32_t* tcuse;
     const int32_t* leaf_refs;
@@ -988,7 +991,7 @@ GI_HD bool visible_wide_begin(const Scene& S, const WN& W, const Ray& ray, doubl
 enum { VIS_DONE = 0, VIS_MORE = 1, VIS_BLOCKED = 2 };
 // does anything in this leaf block the segment?  (the triangle loop of RayTracer::visible for one leaf of the walk)
 template <int FEAT, class WN>
-GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, int32_t lnode, int lslot, int32_t first, int32_t cnt)
+GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, double mt, const Rng& rng, uint32_t light_index, int32_t lnode, int lslot, int32_t first, int32_t cnt, const double* boxes)
 {
     GI_DIV(W, 2);
     W.tick_leaf();
@@ -1012,11 +1015,11 @@ GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, doub
     if (leaf_is_wave_uniform(first, cnt, first_u, cnt_u)) {
         bool hit = false;
         const double tc = sqrt(mt) * (1.0 + 1e-9);
-        if (S.leaf_boxes) W.tick_ebox((uint32_t)cnt_u);
+        if (boxes) W.tick_ebox((uint32_t)cnt_u);
         for (int32_t j = 0; j < cnt_u; j++) {     // wave-uniform trip count: the record address stays scalar
             bool touch = !hit;
-            if (S.leaf_boxes) {                   // (wave-uniform branch) fetch the record only when a lane that still looks for a blocker touches the entity's box
-                const Box6 bx = leaf_box_scalar(S.leaf_boxes + (size_t)(first_u + j) * 6);
+            if (boxes) {                          // (wave-uniform branch) fetch the record only when a lane that still looks for a blocker touches the entity's box
+                const Box6 bx = leaf_box_scalar(boxes + (size_t)(first_u + j) * 6);
                 touch = touch && !entity_box_missed(bx.b, ray, tc);
                 if (__ballot(touch) == 0ull) continue;
             }
@@ -1028,8 +1031,8 @@ GI_HD bool visible_leaf_blocks(const Scene& S, const WN& W, const Ray& ray, doub
         return hit;
     }
 #endif
-    if (S.leaf_boxes && cnt <= 32) {
-        uint32_t m = entity_survivors(S.leaf_boxes, first, cnt, ray, sqrt(mt) * (1.0 + 1e-9));   // a blocker lies before the light: 0 < |hit - o|^2 < mt
+    if (boxes && cnt <= 32) {
+        uint32_t m = entity_survivors(boxes, first, cnt, ray, sqrt(mt) * (1.0 + 1e-9));   // a blocker lies before the light: 0 < |hit - o|^2 < mt
         W.tick_ebox((uint32_t)cnt);
         while (m) {
             const int j = __builtin_ctz(m);
@@ -1051,7 +1054,7 @@ GI_HD int visible_wide_step(const Scene& S, const WN& W, const Ray& ray, double 
     int32_t lnode = 0, first = 0, cnt = 0;
     int lslot = 0;
     if (!wwalk_next_leaf(W, v.k, ray, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt)) return VIS_DONE;
-    return visible_leaf_blocks<FEAT>(S, W, ray, mt, rng, light_index, lnode, lslot, first, cnt) ? VIS_BLOCKED : VIS_MORE;
+    return visible_leaf_blocks<FEAT>(S, W, ray, mt, rng, light_index, lnode, lslot, first, cnt, S.leaf_boxes) ? VIS_BLOCKED : VIS_MORE;
 }
 // what visible() asks of the medium once nothing solid blocks the segment: include/raytracer.h:308-316
 template <int FEAT>

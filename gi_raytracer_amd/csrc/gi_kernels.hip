@@ -193,11 +193,12 @@ extern "C" int gi_debug_div(unsigned long long* out, int reset)
 #endif
 template <int G> struct LdsWideCoop : LdsWide { static constexpr bool kCoop = true; static constexpr int kGroup = G; };   // the same records, one ray per group of G lanes (gi_device.h: trace_wide_coop)
 template <bool COUNT = false>
-__device__ __forceinline__ LdsWideT<COUNT> stage_wide_in_lds(const Scene& S, bool with_boxes = false, int boxes_cap = GI_LDS_WNODES_BIG, bool trace_tables = false)
+__device__ __forceinline__ LdsWideT<COUNT> stage_wide_in_lds(const Scene& S, bool with_boxes = false, int boxes_cap = GI_LDS_WNODES_BIG, int tables = 0)
 {
+    // tables: whose content boxes -- 0 the whole entities' (any walk), 1 the closest-hit walk's, 2 those for segments that end at a light
     LdsWideT<COUNT> N;
     N.g = S.wnodes;
-    N.cboxes = trace_tables ? S.tcboxes : S.cboxes; N.cuse = trace_tables ? S.tcuse : S.cuse;
+    N.cboxes = tables == 1 ? S.tcboxes : (tables == 2 ? S.scboxes : S.cboxes); N.cuse = tables == 1 ? S.tcuse : (tables == 2 ? S.scuse : S.cuse);
     const int cap = with_boxes ? boxes_cap : GI_LDS_WNODES;
     N.box_off = GI_LDS_CBOX_OFF(cap); N.use_off = GI_LDS_CUSE_OFF(cap);
     N.n_l = S.n_wnode < cap ? S.n_wnode : cap;
@@ -221,7 +222,7 @@ template <bool COUNT> struct LdsSrc<0, COUNT> { typedef LdsNodes type; static __
                          static __device__ __forceinline__ LdsNodes stage_for_trace(const Scene& S) { return stage_nodes_in_lds(S); } };
 template <bool COUNT> struct LdsSrc<1, COUNT> { typedef LdsWideT<COUNT> type; static __device__ __forceinline__ type stage(const Scene& S) { return stage_wide_in_lds<COUNT>(S); }
                          static __device__ __forceinline__ type stage_with_boxes(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true); }
-                         static __device__ __forceinline__ type stage_for_trace(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true, GI_LDS_WNODES_BIG, true); } };   // the closest-hit walk's own content boxes
+                         static __device__ __forceinline__ type stage_for_trace(const Scene& S) { return stage_wide_in_lds<COUNT>(S, true, GI_LDS_WNODES_BIG, 1); } };   // the closest-hit walk's own content boxes
 // what the streaming kernels executed in one frame (gi_get_stream_counters): per-lane WalkCnt sums of k_st_trace and k_st_shadow, the rays handed
 // to each, the gather's queries and the candidates they scanned
 struct StreamCounters { unsigned long long trace[7], trace_rays, shadow[7], shadow_rays, gather_queries, gather_cand; };
@@ -798,7 +799,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
     uint32_t li = 0;   // the light this lane's walk is about
     unsigned int* const s_next = reinterpret_cast<unsigned int*>(gi_dyn_lds + GI_LDS_BIG_CNT_OFF);
     if (threadIdx.x == 0) *s_next = 0u;
-    const LdsWideT<COUNT> N = stage_wide_in_lds<COUNT>(S, true);   // ends with a barrier
+    const LdsWideT<COUNT> N = stage_wide_in_lds<COUNT>(S, true, GI_LDS_WNODES_BIG, 2);   // ends with a barrier; every segment of this kernel ends at a light
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_in = ctl->n_shade, bs = (uint32_t)GI_TRACE_CHUNK;
     uint32_t n_rays = 0;   // COUNT: shadow segments this lane walked
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
         if (lf != 0ull && ((uint32_t)__popcll(lf) >= leaf_min || __ballot(walking && !at_leaf) == 0ull)) {
             if (walking && at_leaf) {
                 at_leaf = false;
-                if (visible_leaf_blocks<FEAT>(S, N, ray, mt, rng, li, lnode, lslot, first, cnt)) { walking = false; pend = true; blocked = true; }
+                if (visible_leaf_blocks<FEAT>(S, N, ray, mt, rng, li, lnode, lslot, first, cnt, S.shadow_boxes)) { walking = false; pend = true; blocked = true; }
             }
         }
         if constexpr (MULTI != 0) {   // this light is hidden: on to the one before it, in the same lane
@@ -1479,6 +1480,7 @@ struct gi_ctx {
     DevBuf<double> d_trace_boxes;         // the closest-hit walk's boxes (gi_device.h: trace_wide_step)
     DevBuf<float> d_tcboxes;              // and the content boxes made of them
     DevBuf<uint32_t> d_tcuse;
+    bool lights_clear = false;            // of the scene last uploaded: no entity within a light's radius + the shadow bias of it (gi_layout.h)
     double cut_margin = -1;               // of the scene last uploaded
     bool scene_clipped = false;           // its trace boxes differ from the whole ones
     bool entity_boxes = true;             // GI_ENTITY_BOXES=0: every entity of a leaf is tested, as the reference does
@@ -1676,6 +1678,11 @@ static void set_walk_shortcuts(gi_ctx* c)
     const bool cut_to_leaves = S.trace_boxes == c->d_trace_boxes.p && S.cboxes && c->d_tcboxes.n == c->d_cboxes.n;
     S.tcboxes = cut_to_leaves ? c->d_tcboxes.p : S.cboxes;
     S.tcuse = cut_to_leaves ? c->d_tcuse.p : S.cuse;
+    // segments that end at a light (k_st_shadow): the same boxes, as long as nothing can block a segment inside its last GI_SHADOW_BIAS (gi_device.h: visible_leaf_blocks)
+    const bool sh = c->lights_clear && S.trace_boxes == c->d_trace_boxes.p;
+    S.shadow_boxes = sh ? S.trace_boxes : S.leaf_boxes;
+    S.scboxes = sh ? S.tcboxes : S.cboxes;
+    S.scuse = sh ? S.tcuse : S.cuse;
 }
 
 int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
@@ -1702,6 +1709,7 @@ int gi_upload_scene(gi_ctx* c, const gi_scene_desc* d)
     HIP_TRY(c, c->d_tcuse.upload(H.tcuse));
     c->cut_margin = H.cut_margin;
     c->scene_clipped = H.clipped;
+    c->lights_clear = H.lights_clear;
     HIP_TRY(c, c->d_tris.upload(H.tris));
     HIP_TRY(c, c->d_shade.upload(H.shade));
     HIP_TRY(c, c->d_mats.upload(H.mats));

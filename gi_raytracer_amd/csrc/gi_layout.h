@@ -31,6 +31,7 @@ struct HostScene {
     std::vector<double> trace_boxes;  // [n_refs][6] for the closest-hit walk: the box of the part of an opaque entity inside its leaf (gi_device.h: trace_wide_step)
     double cut_margin = -1;           // what the closest-hit walk's short cuts allow for rounding (1e-5 of the scene)
     bool clipped = false;             // trace_boxes differs from leaf_boxes
+    bool lights_clear = false;        // no entity's box within a light's radius + twice the shadow bias (+ 4 margins) of the light: nothing can block a shadow segment in its last stretch
     std::vector<float> tcboxes;       // content boxes made of the trace boxes: what the closest-hit walk culls by (like cboxes; empty when !clipped)
     std::vector<uint32_t> tcuse;
     std::vector<int32_t> worder;      // canonical node of every wide record
@@ -459,6 +460,26 @@ inline bool layout_scene(const gi_scene_desc* d, HostScene& H, std::string& err)
         }
         H.tcboxes.clear(); H.tcuse.clear();
         if (H.clipped && !H.wnodes.empty()) layout_cboxes(d, H, H.trace_boxes.data(), H.tcboxes, H.tcuse);
+        // RayTracer::visible walks a segment up to GI_SHADOW_BIAS before the light but lets anything up to the light itself block it
+        // (include/raytracer.h:290-305): a hit in that last stretch is only found from leaves the walk meets earlier.  Where no entity comes that
+        // near a light (every scene of the reference: lights hang in free space) the stretch is empty and the leaf-cut boxes serve shadow segments too.
+        H.lights_clear = d->n_light > 0;
+        for (int li = 0; li < d->n_light; li++) {
+            const double* l = d->lights + (size_t)li * 11;
+            const double R = l[6] + 2 * GI_SHADOW_BIAS + 4 * wide;
+            for (int e = 0; e < d->n_tri && H.lights_clear; e++) {
+                const double* P = d->tri_pos + (size_t)e * 9;
+                double d2 = 0;
+                for (int ax = 0; ax < 3; ax++) {
+                    const bool sph = d->ent_kind && d->ent_kind[e] == 1;
+                    const double lo = sph ? P[ax] - P[3] : std::min(P[ax], std::min(P[3 + ax], P[6 + ax]));
+                    const double hi = sph ? P[ax] + P[3] : std::max(P[ax], std::max(P[3 + ax], P[6 + ax]));
+                    const double g = l[ax] < lo ? lo - l[ax] : (l[ax] > hi ? l[ax] - hi : 0.0);
+                    d2 += g * g;
+                }
+                if (!(d2 > R * R)) H.lights_clear = false;
+            }
+        }
     }
     H.mats.resize((size_t)d->n_mat);
     for (int i = 0; i < d->n_mat; i++) {

@@ -28,7 +28,7 @@ def lib():
         L.emul_upload_photons.argtypes = [vp, C.POINTER(gi.PhotonMapDesc)]
         L.emul_trace.argtypes = [vp, C.c_int, _dp, _ip, _ip, _dp]
         L.emul_visible.argtypes = [vp, C.c_int, _dp, _ip]
-        L.emul_visible_turns.argtypes = [vp, C.c_int, _dp, _ip]
+        L.emul_visible_turns.argtypes = [vp, C.c_int, _dp, _ip, C.c_int]
         L.emul_gather.argtypes = [vp, C.c_int, _dp, _dp, _ip]
         L.emul_radiance.argtypes = [vp, C.c_int, _dp, _up, C.c_uint64, _dp]
         L.emul_render.argtypes = [vp, C.POINTER(gi.RenderParams), _dp, _ip, C.POINTER(C.c_int64)]
@@ -133,10 +133,10 @@ class EmulRayTracer(gi.RayTracer):
         self.E.emul_visible(self.h, len(q), gi._p(q), gi._p(vis, _ip))
         return vis
 
-    def visible_turns(self, q):
+    def visible_turns(self, q, light_bound=False):
         """visible() as k_st_shadow walks it (turn by turn); None when the scene has no wide records."""
         q = gi._f64(q).reshape(-1, 6); vis = np.zeros(len(q), np.int32)
-        if self.E.emul_visible_turns(self.h, len(q), gi._p(q), gi._p(vis, _ip)) != 0:
+        if self.E.emul_visible_turns(self.h, len(q), gi._p(q), gi._p(vis, _ip), 1 if light_bound else 0) != 0:
             return None
         return vis
 

@@ -37,6 +37,10 @@ struct Emul {
         const bool cut_to_leaves = S.cboxes && S.trace_boxes == hs.trace_boxes.data() && hs.tcboxes.size() == hs.cboxes.size();   // (gi_kernels.hip: set_walk_shortcuts)
         S.tcboxes = cut_to_leaves ? hs.tcboxes.data() : S.cboxes;
         S.tcuse = cut_to_leaves ? hs.tcuse.data() : S.cuse;
+        const bool sh = hs.lights_clear && S.trace_boxes == hs.trace_boxes.data();
+        S.shadow_boxes = sh ? S.trace_boxes : S.leaf_boxes;
+        S.scboxes = sh ? S.tcboxes : S.cboxes;
+        S.scuse = sh ? S.tcuse : S.cuse;
         S.tri_uv = hs.tri_uv.data(); S.texs = hs.texs.data(); S.tex_pixels = hs.tex_pixels.data(); S.tex_lut = hs.tex_lut.data(); S.n_tex = hs.n_tex();
         S.fogs = hs.fogs.data(); S.fog_grid = hs.fog_grid.data(); S.n_fog = hs.n_fog();
         for (int k = 0; k < 3; k++) S.ambient[k] = hs.ambient[k];
@@ -96,11 +100,12 @@ int emul_visible(Emul* e, int n, const double* q, int32_t* vis)
 }
 // RayTracer::visible the way k_st_shadow walks it: one turn at a time (wwalk_turn), a leaf's triangles when the walk stands on one
 // (visible_leaf_blocks), the medium at the end -- must answer as visible() does.  -1: the scene has no wide records.
-int emul_visible_turns(Emul* e, int n, const double* q, int32_t* vis)
+// light_bound: the segments end at a light (what k_st_shadow is given): the boxes and content boxes it uses for them
+int emul_visible_turns(Emul* e, int n, const double* q, int32_t* vis, int light_bound)
 {
     if (!e->S.wnodes) return -1;
     GlobalWide W;
-    W.g = e->S.wnodes; W.cboxes = e->S.cboxes; W.cuse = e->S.cuse;
+    W.g = e->S.wnodes; W.cboxes = light_bound ? e->S.scboxes : e->S.cboxes; W.cuse = light_bound ? e->S.scuse : e->S.cuse;
     for (int i = 0; i < n; i++) {
         const double* p = q + (size_t)i * 6;
         V3 o = v3(p[0], p[1], p[2]), t = v3(p[3], p[4], p[5]);
@@ -116,7 +121,7 @@ int emul_visible_turns(Emul* e, int n, const double* q, int32_t* vis)
                 int lslot = 0;
                 const int r = wwalk_turn(W, v.k, sr, v.wr, 0.0, v.tmax, lnode, lslot, first, cnt);
                 if (r == WALK_END) break;
-                if (r == WALK_LEAF && visible_leaf_blocks<7>(e->S, W, sr, mt, rng, 0u, lnode, lslot, first, cnt)) { blocked = true; break; }
+                if (r == WALK_LEAF && visible_leaf_blocks<7>(e->S, W, sr, mt, rng, 0u, lnode, lslot, first, cnt, light_bound ? e->S.shadow_boxes : e->S.leaf_boxes)) { blocked = true; break; }
             }
         }
         vis[i] = !blocked && visible_through_fog<7>(e->S, sr, mt, rng, 0u);

@@ -63,6 +63,18 @@ def test_turn_wise_shadow_walk_answers_like_visible(setup):
         pytest.skip("no wide records for this tree")
     assert np.array_equal(turns, rt.visible(q))
     assert 0 < turns.sum() < len(turns)
+    # segments that end at a light, from surface points and from anywhere: k_st_shadow's own boxes (cut to the leaves where no entity comes near a light)
+    lights = scene.tables()["lights"].reshape(-1, 11)
+    if len(lights):
+        hit, _, res = rt.trace(rays)
+        org = np.concatenate([res[hit > 0, :3] + 1e-4 * res[hit > 0, 3:6], rays[:, :3]])
+        rs = np.random.RandomState(4)
+        u = rs.randn(len(org), 3)
+        u /= np.linalg.norm(u, axis=1)[:, None]
+        ql = np.concatenate([org, lights[0, :3] + lights[0, 6] * u], axis=1)
+        lb = rt.visible_turns(ql, light_bound=True)
+        assert np.array_equal(lb, rt.visible(ql))
+        assert 0 < lb.sum() < len(lb)
 
 
 def test_wide_walk_on_a_deeper_tree():
