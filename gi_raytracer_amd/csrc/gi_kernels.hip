@@ -715,6 +715,8 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
     if constexpr (COUNT) { flush_walk_cnt(sc->trace, N.wc); flush_u64(&sc->trace_rays, n_rays); }
 }
 
+__global__ void k_iota(uint32_t* v, uint32_t n) { for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i; }
+
 // the walk-free instance fits its registers at 2 waves per SIMD without a spill and runs faster that way (128.. VGPRs, 4 waves: 260 B of
 // scratch per lane, 144 ms on the benchmark; 3 waves 128 ms; 2 waves 128 ms) -- with no walk in it there is little latency left to hide
 #ifndef GI_DEFER_WAVES
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
 template <int FEAT, int WIDE, int DEFER>
 __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, const StreamCtl* ctl, unsigned int* bc, uint32_t* segs, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, double* g_pos,
-                                                       uint32_t* q_free, double* lbuf, ShadowQ* shq)
+                                                       uint32_t* q_free, double* lbuf, ShadowQ* shq, const uint32_t* q_orig)
 {
     // the waves of a workgroup take its items 64 at a time from a counter in LDS (in the 128 bytes the wide records leave free) instead of
     // a fixed share each: a wave that drew cheap items takes more of them
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
             slot = q_shade[i];
             if constexpr (DEFER != 0) {
                 const int nl = DEFER == 2 ? S.n_light : 1;          // one query per light, the queries of item i side by side
-                ShadowQ* const e = shq + (size_t)i * (size_t)nl;
+                ShadowQ* const e = shq + (size_t)(q_orig ? q_orig[i] : i) * (size_t)nl;   // q_orig: the item's place in the queue the shadow kernel follows (the trace stage's order)
                 fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, pool[slot], seed, nullptr, &so, nullptr, e);
                 for (int li = 0; li < nl; li++) { e[li].idx = (uint32_t)(slot_sample[slot] - sample0); e[li].slot = slot; }
             } else
@@ -1469,6 +1471,8 @@ struct gi_ctx {
     DevBuf<uint32_t> d_cuse;
     bool cull_enabled = true;         // gi_set_content_culling
     bool sort_cont = true;            // GI_SORT_CONT=0: continuing rays stay in queue order
+    bool sort_shade = true;           // GI_SORT_SHADE=0: the shade stage takes a pass of continuing rays in the order the trace stage left them
+    int sort_shade_lo = 5;            // GI_SORT_SHADE_LO: lowest slot bit that sort looks at (32 neighbouring records = 7 KB stay in the trace stage's order)
     int sort_lo_bit = 0;              // GI_SORT_LO_BIT: lowest key bit the sort of the continuing rays looks at (27-bit key: octant, 18 Morton bits, 6 direction bits)
     uint32_t refill_min = 32;         // GI_REFILL_MIN: idle lanes of a wave that make k_st_trace hand out new rays (64: lockstep waves)
     bool wide_enabled = true;         // gi_set_wide_nodes
@@ -1623,6 +1627,8 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
+    if (const char* e = getenv("GI_SORT_SHADE")) c->sort_shade = atoi(e) != 0;
+    if (const char* e = getenv("GI_SORT_SHADE_LO")) c->sort_shade_lo = std::max(0, atoi(e));
     if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
     if (const char* e = getenv("GI_DEFER_SHADOWS")) c->defer_shadows = atoi(e) != 0;
     if (const char* e = getenv("GI_FAST_DESCENT")) c->fast_descent = atoi(e) != 0;
@@ -2011,6 +2017,24 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
             job.kind[2] = -1; job.gather_queue = -1;
             stage_begin(c, STG_OTHER); hipLaunchKernelGGL(k_st_compact, dim3(G.compact), dim3(256), 0, st, c->S, job, bc, c->d_segs.p, (uint32_t)G.trace, ctl); stage_end(c);
         }
+        // A pass of continuing rays leaves the trace stage in the rays' coherence order, which scatters the shade stage's reads and writes of
+        // the path records over the whole pool.  The shade queue is put into slot order for it (a radix sort of slot / place pairs); the shadow
+        // queries still land at the place the trace stage gave the item, so the shadow walks keep that (coherent) order.
+        const uint32_t* q_shade_use = q_shade;
+        const uint32_t* q_orig = nullptr;
+        if (c->sort_shade && n_cont > 0) {
+            int sbits = 1;
+            while ((1ull << sbits) < (unsigned long long)c->d_pool.n) sbits++;
+            uint32_t* const tk = reinterpret_cast<uint32_t*>(c->d_sort_tmp.p);
+            const uint32_t bound = n_prepared + n_cont;
+            stage_begin(c, STG_SORT);
+            hipLaunchKernelGGL(k_iota, dim3(std::min<uint32_t>((bound + 1023u) / 1024u, 4096u)), dim3(1024), 0, st, c->d_gv[0].p, bound);
+            const int rc = rs_sort_pairs(c, q_shade, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, tk, tk + bound, bound, reinterpret_cast<const uint32_t*>(&ctl->n_shade), std::min(c->sort_shade_lo, sbits - 1), sbits, c->d_rs_hist.p);
+            if (rc) return rc;
+            stage_end(c);
+            q_shade_use = c->d_gk[1].p;
+            q_orig = c->d_gv[1].p;
+        }
         ShadowQ* const shq = defers_shadows(c) ? c->d_shq.p : nullptr;
         // shade: continuing rays (slot + key) -> staging 0 / 1, gather queries (slot + position) -> staging 2 / pos, finished paths -> staging 3
         HIP_TRY(c, hipMemsetAsync(bc, 0, bc_bytes, st));
@@ -2018,8 +2042,8 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         auto shade_kernel = shq ? (many ? (tex ? k_st_shade<7, 1, 2> : fog ? k_st_shade<3, 1, 2> : sph ? k_st_shade<GI_FEAT_SPHERES, 1, 2> : k_st_shade<0, 1, 2>)
                                         : (tex ? k_st_shade<7, 1, 1> : fog ? k_st_shade<3, 1, 1> : sph ? k_st_shade<GI_FEAT_SPHERES, 1, 1> : k_st_shade<0, 1, 1>))
                                 : tex ? (wide ? k_st_shade<7, 1, 0> : k_st_shade<7, 0, 0>) : wide ? (fog ? k_st_shade<3, 1, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 1, 0> : k_st_shade<0, 1, 0>)) : (fog ? k_st_shade<3, 0, 0> : (sph ? k_st_shade<GI_FEAT_SPHERES, 0, 0> : k_st_shade<0, 0, 0>));
-        stage_begin(c, STG_SHADE); hipLaunchKernelGGL(shade_kernel, dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade, ctl, bc, c->d_segs.p,
-                           c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf, shq);
+        stage_begin(c, STG_SHADE); hipLaunchKernelGGL(shade_kernel, dim3(G.shade), dim3(GI_SHADE_BLOCK), kLdsNodes, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0, q_shade_use, ctl, bc, c->d_segs.p,
+                           c->d_stage[0].p, c->d_stage[1].p, c->d_stage[2].p, c->d_stage_pos.p, c->d_stage[3].p, lbuf, shq, q_orig);
         stage_end(c);
         if (shq) {   // the walks it put off; before the gather of the same vertices (the order in which a path's radiance is summed)
             stage_begin(c, STG_SHADOW);
