@@ -62,7 +62,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "gi_create", "gi_destroy", "gi_last_error", "gi_set_stream", "gi_upload_scene", "gi_upload_photons", "gi_local_rows",
     "gi_render_device", "gi_render_host", "gi_set_render_mode", "gi_set_wide_nodes", "gi_set_content_culling", "gi_set_entity_boxes", "gi_set_pool_slots", "gi_last_render_ms", "gi_last_stage_ms", "gi_last_kernel_ms", "gi_set_counters", "gi_get_counters", "gi_get_stream_counters", "gi_trace", "gi_visible",
-    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_debug_sort_pairs", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
+    "gi_gather", "gi_radiance", "gi_emit_photons", "gi_halton_sample", "gi_halton_index", "gi_debug_leaf_order", "gi_debug_sort_pairs", "gi_debug_find_leaves", "gi_kat", "gi_visible_rays", "gi_build_photon_map", "gi_trace_photons", "gi_debug_photon_tables", "gi_clear_photons", "gi_group_clear_photons",
     "gi_device_count", "gi_group_create", "gi_group_destroy", "gi_group_size", "gi_group_ctx", "gi_group_last_error", "gi_group_upload_scene", "gi_group_upload_photons", "gi_group_render_host", "gi_group_render_device",
     "gih_scene_create", "gih_scene_destroy", "gih_last_error", "gih_load_scn", "gih_add_material", "gih_add_triangles",
     "gih_add_texture", "gih_add_material_tex", "gih_load_png", "gih_free",
@@ -110,6 +110,7 @@ def lib():
     L.gi_halton_index.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, _up, _up]
     L.gi_debug_leaf_order.argtypes = [vp, C.c_int32, _dp, C.c_int32, _ip, _ip]
     L.gi_debug_sort_pairs.argtypes = [vp, C.c_int32, _up, _up, C.c_int32, C.c_int32, _up, _up]
+    L.gi_debug_find_leaves.argtypes = [vp, C.c_int32, _dp, _ip, _ip]
     L.gi_kat.argtypes = [vp, C.c_int32, C.c_int32, _dp, C.c_int32, _dp]
     L.gi_clear_photons.argtypes = [vp]
     L.gi_group_clear_photons.argtypes = [vp]
@@ -621,6 +622,13 @@ class RayTracer:
         ko = np.zeros_like(k); vo = np.zeros_like(v)
         self._check(self.L.gi_debug_sort_pairs(self.h, len(k), _p(k, _up), _p(v, _up), begin_bit, end_bit, _p(ko, _up), _p(vo, _up)), "sort_pairs")
         return ko, vo
+
+    def find_leaves(self, pos):
+        """gi_debug_find_leaves: (fast, full) photon-map leaf of each position; fast = -2 where the quick descent declines."""
+        p = _f64(pos).reshape(-1, 3)
+        a = np.zeros(len(p), np.int32); b = np.zeros(len(p), np.int32)
+        self._check(self.L.gi_debug_find_leaves(self.h, len(p), _p(p), _p(a, _ip), _p(b, _ip)), "find_leaves")
+        return a, b
 
     def leaf_order(self, rays, cap=256):
         """Octree::intersectSorted as the device walk produces it: per ray the pre-order indices of the non-empty leaves in visiting order."""

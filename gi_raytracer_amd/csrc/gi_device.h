@@ -162,6 +162,8 @@ struct Scene {
     double ambient[3];
     double root_bmin[3], root_bmax[3];   // box of octree node 0 (kernel argument: no memory round trip before a walk starts)
     double pmap_bmin[3], pmap_bmax[3];   // box of the photon map's root (gather_find_leaf_fast)
+    const int32_t* pjump;     // [32][32][32] (y, z, x) the node the descent of a position in that cell of the map's box has reached after five levels (or its leaf); null = not used
+    double pjump_cell[3], pjump_inv[3];   // a cell's size per axis and its inverse
     double cut_margin;        // >= 0: a closest-hit walk looks no further than its best hit plus this (trace_wide_step); < 0: it walks on as the reference does
 };
 
@@ -1518,6 +1520,22 @@ GI_HD int32_t gather_find_leaf_fast(const Scene& S, V3 pos)
     const double eps = 1e-12 * ext;
     for (int ax = 0; ax < 3; ax++) if (!(p[ax] > S.pmap_bmin[ax] + eps && p[ax] < S.pmap_bmax[ax] - eps)) return -2;
     int32_t node = 0;
+    if (S.pjump) {
+        // the first five levels at once: the cell of a 32^3 grid over the map's box the position lies in names the node its descent reaches (the split
+        // planes of those levels were checked against the grid's when the table was made: within 1e-12 of the extent); a position within 4 eps of a cell's
+        // face starts at the root instead
+        int cell[3];
+        bool clear = true;
+        for (int ax = 0; ax < 3; ax++) {
+            const double f = (p[ax] - S.pmap_bmin[ax]) * S.pjump_inv[ax];
+            int i = (int)f;
+            i = i < 0 ? 0 : (i > 31 ? 31 : i);
+            const double lo = S.pmap_bmin[ax] + (double)i * S.pjump_cell[ax];
+            if (!(p[ax] - lo > 4.0 * eps && lo + S.pjump_cell[ax] - p[ax] > 4.0 * eps)) clear = false;
+            cell[ax] = i;
+        }
+        if (clear) node = S.pjump[(cell[1] * 32 + cell[2]) * 32 + cell[0]];
+    }
     for (;;) {
         const PDescent nd = S.pdescent[node];
         if (nd.first_child < 0) return node;

@@ -948,6 +948,37 @@ __global__ __launch_bounds__(256) void k_pdescent(const PNode* nodes, int32_t n,
     d.first_child = nodes[i].first_child; d.pad = 0;
     out[i] = d;
 }
+// The jump table of gather_find_leaf_fast: for every cell of a 32^3 grid over the map's box the node five levels down (or the leaf above that) on the way of
+// the cell's centre.  *bad is raised when a split plane met on the way is not the grid's plane of that level to within 1e-12 of the extent (the reference
+// computes "the middle" in three ways that differ in the last bit, no more): the table is then not used.
+__global__ __launch_bounds__(256) void k_pjump(const PDescent* pd, const double* bmin3, const double* cell3, double eps, int32_t* out, int* bad)
+{
+    const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= 32 * 32 * 32) return;
+    const int cell[3] = {i & 31, i >> 10, (i >> 5) & 31};       // x fastest, then z, then y
+    int32_t node = 0;
+    for (int level = 0; level < 5; level++) {
+        const PDescent nd = pd[node];
+        if (nd.first_child < 0) break;
+        int k = 0;
+        for (int ax = 0; ax < 3; ax++) {
+            const int top = cell[ax] >> (4 - level);                                        // the cell's index among this level's 2^(level+1) halves
+            const double plane = bmin3[ax] + (double)(((top >> 1) * 2 + 1) << (4 - level)) * cell3[ax];   // the grid's middle of the node's interval
+            if (!(fabs(nd.mid[ax] - plane) <= eps)) *bad = 1;
+            if (top & 1) k |= ax == 0 ? 1 : (ax == 2 ? 2 : 4);
+        }
+        node = nd.first_child + k;
+    }
+    out[i] = node;
+}
+__global__ void k_find_leaves(Scene S, int32_t n, const double* pos, int32_t* fast, int32_t* full)   // gi_debug_find_leaves
+{
+    for (int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += (int32_t)(gridDim.x * blockDim.x)) {
+        const V3 p = v3(pos[(size_t)i * 3], pos[(size_t)i * 3 + 1], pos[(size_t)i * 3 + 2]);
+        fast[i] = S.pdescent ? gather_find_leaf_fast(S, p) : -2;
+        full[i] = gather_find_leaf(S, p);
+    }
+}
 struct CompactStream { const uint32_t* src; uint32_t* dst; int width; };
 struct CompactJob {
     CompactStream st[5];    // streams of queue A (e.g. slot + key), then queue B, queue C: n_streams[q] streams each
@@ -1470,6 +1501,9 @@ struct gi_ctx {
     DevBuf<float> d_cboxes;           // content boxes of the wide records' children
     DevBuf<uint32_t> d_cuse;
     bool cull_enabled = true;         // gi_set_content_culling
+    bool descent_jump = true;         // GI_DESCENT_JUMP=0: the fast descent of the gather keys starts at the root
+    DevBuf<int32_t> d_pjump;          // its jump table (gi_device.h: gather_find_leaf_fast)
+    DevBuf<double> d_pjump_aux;
     bool sort_cont = true;            // GI_SORT_CONT=0: continuing rays stay in queue order
     bool sort_shade = true;           // GI_SORT_SHADE=0: the shade stage takes a pass of continuing rays in the order the trace stage left them
     int sort_shade_lo = 5;            // GI_SORT_SHADE_LO: lowest slot bit that sort looks at (32 neighbouring records = 7 KB stay in the trace stage's order)
@@ -1573,7 +1607,7 @@ int fail(gi_ctx* c, int code, const std::string& msg)
 static int install_pleaf_rank(gi_ctx* c)
 {
     Scene& S = c->S;
-    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0; S.pdescent = nullptr;
+    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0; S.pdescent = nullptr; S.pjump = nullptr;
     if (S.n_pnode <= 0) return GI_OK;
     if (c->d_pleaf_rank.n < (size_t)S.n_pnode) { HIP_TRY(c, c->d_pleaf_rank.alloc((size_t)S.n_pnode)); HIP_TRY(c, c->d_prank_leaf.alloc((size_t)S.n_pnode)); }
     if (!c->d_n_pleaf.p) HIP_TRY(c, c->d_n_pleaf.alloc(1));
@@ -1593,6 +1627,25 @@ static int install_pleaf_rank(gi_ctx* c)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (int k = 0; k < 3; k++) { S.pmap_bmin[k] = root.bmin[k]; S.pmap_bmax[k] = root.bmax[k]; }
         S.pdescent = c->d_pdescent.p;
+        S.pjump = nullptr;
+        if (c->descent_jump) {
+            double ext = 0.0, host[7];
+            for (int k = 0; k < 3; k++) { ext = std::max(ext, root.bmax[k] - root.bmin[k]); S.pjump_cell[k] = (root.bmax[k] - root.bmin[k]) / 32.0; S.pjump_inv[k] = 32.0 / (root.bmax[k] - root.bmin[k]); }
+            bool ok = ext > 0.0;
+            for (int k = 0; k < 3; k++) { host[k] = root.bmin[k]; host[3 + k] = S.pjump_cell[k]; if (!(S.pjump_cell[k] > 0.0) || !std::isfinite(S.pjump_inv[k])) ok = false; }
+            if (ok) {
+                if (c->d_pjump.n < 32768) HIP_TRY(c, c->d_pjump.alloc(32768));
+                if (c->d_pjump_aux.n < 8) HIP_TRY(c, c->d_pjump_aux.alloc(8));
+                host[6] = 0.0;                                                    // (as an int: the "bad" flag)
+                HIP_TRY(c, hipMemcpyAsync(c->d_pjump_aux.p, host, sizeof host, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(k_pjump, dim3(128), dim3(256), 0, c->stream, c->d_pdescent.p, c->d_pjump_aux.p, c->d_pjump_aux.p + 3, 1e-12 * ext, c->d_pjump.p, reinterpret_cast<int*>(c->d_pjump_aux.p + 6));
+                HIP_TRY(c, hipGetLastError());
+                int bad = 1;
+                HIP_TRY(c, hipMemcpyAsync(&bad, c->d_pjump_aux.p + 6, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (!bad) S.pjump = c->d_pjump.p;
+            }
+        }
     }
     return GI_OK;
 }
@@ -1627,6 +1680,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
+    if (const char* e = getenv("GI_DESCENT_JUMP")) c->descent_jump = atoi(e) != 0;
     if (const char* e = getenv("GI_SORT_SHADE")) c->sort_shade = atoi(e) != 0;
     if (const char* e = getenv("GI_SORT_SHADE_LO")) c->sort_shade_lo = std::max(0, atoi(e));
     if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
@@ -2597,6 +2651,24 @@ int gi_debug_sort_pairs(gi_ctx* c, int32_t n, const uint32_t* keys, const uint32
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(keys_out, d[2].p, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(vals_out, d[3].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GI_OK;
+}
+
+int gi_debug_find_leaves(gi_ctx* c, int32_t n, const double* pos, int32_t* fast_out, int32_t* full_out)
+{
+    if (!c || n < 0 || (n && (!pos || !fast_out || !full_out))) return GI_E_INVALID;
+    if (c->S.n_pnode <= 0) return fail(c, GI_E_STATE, "find_leaves: no photon map");
+    if (n == 0) return GI_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevBuf<double> d_p;
+    DevBuf<int32_t> d_a, d_b;
+    HIP_TRY(c, d_p.upload(std::vector<double>(pos, pos + (size_t)n * 3)));
+    HIP_TRY(c, d_a.alloc(n)); HIP_TRY(c, d_b.alloc(n));
+    hipLaunchKernelGGL(k_find_leaves, GI_GRID(n), 0, c->stream, c->S, n, d_p.p, d_a.p, d_b.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(fast_out, d_a.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(full_out, d_b.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GI_OK;
 }
 

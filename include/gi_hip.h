@@ -234,6 +234,10 @@ int gi_debug_leaf_order(gi_ctx*, int32_t n, const double* rays, int32_t cap, int
 /* gi_debug_sort_pairs: the pipeline's own radix sort (gi_sort.inc: the gather queries by photon-map leaf, the continuing rays by coherence key) on
  * caller data -- n (key, value) pairs sorted by bits [begin_bit, end_bit) of the key, stable.  Host pointers.                                */
 int gi_debug_sort_pairs(gi_ctx*, int32_t n, const uint32_t* keys, const uint32_t* vals, int32_t begin_bit, int32_t end_bit, uint32_t* keys_out, uint32_t* vals_out);
+/* gi_debug_find_leaves: the photon-map leaf around each position (PhotonMap::Node::getBounds, include/photonMap.cpp:115-134) as the two descents of the
+ * pipeline find it: full_out the one that asks every box on the way (-1: no leaf contains the position), fast_out the one the gather keys of a pass
+ * take (split records only, the first five levels through a jump table), -2 where that one declines (a position within 1e-12 of a split plane). */
+int gi_debug_find_leaves(gi_ctx*, int32_t n, const double* pos, int32_t* fast_out, int32_t* full_out);
 int gi_kat(gi_ctx*, int32_t what, int32_t n, const double* in, int32_t in_stride, double* out3);
 
 

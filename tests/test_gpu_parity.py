@@ -181,8 +181,8 @@ def test_schedule_knobs_change_nothing(name, monkeypatch):
     to the put-off segment.  GI_COOP_FACTOR moves the finisher between one path per lane, per group of 16 lanes and per wave."""
     scene = pc.two_light_scene(name.endswith("glass")) if name.startswith("two_lights") else pc.load_scene(name)   # two lights: one put-off query per light
     frames = []
-    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}, {"GI_ENTITY_BOXES": "0"}, {"GI_CLIP_BOXES": "0"}, {"GI_WALK_CUT": "0"}, {"GI_SORT_CONT": "0"}, {"GI_SORT_SHADE": "0"}, {"GI_SORT_SHADE_LO": "0"}, {"GI_FAST_DESCENT": "0"}):
-        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR", "GI_ENTITY_BOXES", "GI_CLIP_BOXES", "GI_WALK_CUT", "GI_SORT_CONT", "GI_SORT_SHADE", "GI_SORT_SHADE_LO", "GI_FAST_DESCENT"):
+    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}, {"GI_ENTITY_BOXES": "0"}, {"GI_CLIP_BOXES": "0"}, {"GI_WALK_CUT": "0"}, {"GI_SORT_CONT": "0"}, {"GI_SORT_SHADE": "0"}, {"GI_SORT_SHADE_LO": "0"}, {"GI_FAST_DESCENT": "0"}, {"GI_DESCENT_JUMP": "0"}):
+        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR", "GI_ENTITY_BOXES", "GI_CLIP_BOXES", "GI_WALK_CUT", "GI_SORT_CONT", "GI_SORT_SHADE", "GI_SORT_SHADE_LO", "GI_FAST_DESCENT", "GI_DESCENT_JUMP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -197,6 +197,34 @@ def test_schedule_knobs_change_nothing(name, monkeypatch):
 def test_photon_octree_descent_variants_agree():
     scene = pc.load_scene("caustics")
     pc.check_photon_descent(gi.RayTracer(0).setScene(scene), scene)
+
+
+@pytest.mark.parametrize("jump", ["1", "0"])
+def test_quick_descent_of_the_gather_keys_finds_the_same_leaf(jump, monkeypatch):
+    """gather_find_leaf_fast (what k_st_compact keys a pass's gather queries with: 32-byte split records, the first five levels through a jump table)
+    against the descent that asks every box on the way, PhotonMap::Node::getBounds (include/photonMap.cpp:115-134): positions all over the map, outside
+    it, exactly on split planes and faces, and 1e-15 .. 1e-9 of the extent beside them.  It may decline (-2), it may not differ."""
+    monkeypatch.setenv("GI_DESCENT_JUMP", jump)
+    scene = pc.load_scene("caustics")
+    rt = gi.RayTracer(0).setScene(scene)
+    rt.tracePhotons(200000)                      # (built on the host and uploaded: the host tables name the planes to aim at)
+    nb = scene.photon_tables()["node_bbox"]
+    root = nb[0]
+    ext = (root[3:] - root[:3]).max()
+    rs = np.random.RandomState(2)
+    pos = root[:3] + (root[3:] - root[:3]) * (rs.rand(400000, 3) * 1.04 - 0.02)
+    k = 100000
+    boxes = nb[rs.randint(len(nb), size=k)]
+    ax = rs.randint(3, size=k)
+    plane = boxes[np.arange(k), ax + 3 * rs.randint(2, size=k)]
+    off = np.where(rs.rand(k) < 0.3, 0.0, ext * 10.0 ** rs.uniform(-15, -9, k) * rs.choice([-1, 1], k))
+    pos[np.arange(k), ax] = plane + off
+    grid = root[:3] + (root[3:] - root[:3]) * rs.randint(0, 33, size=(k, 3)) / 32.0      # the jump table's own cell faces
+    pos[k:2 * k][np.arange(k), ax] = grid[np.arange(k), ax] + off
+    fast, full = rt.find_leaves(pos)
+    took = fast != -2
+    assert np.array_equal(fast[took], full[took])
+    assert took.mean() > 0.6 and (~took).sum() > 1000 and (full == -1).any()
 
 
 def test_gather_matches_reference_table(setup):
