@@ -939,6 +939,28 @@ __global__ __launch_bounds__(1024) void k_pleaf_rank(const PNode* nodes, int32_t
     }
     if (threadIdx.x == 0) *n_out = base;
 }
+// The candidate lists written out (k_st_gather stages a leaf's candidates 64 at a time, one per lane: a lane that has to find "candidate number k" by
+// walking the leaf's range list reads its range records one after the other; k_st_gather_wave deals a leaf's candidates to the lanes of a wave).
+__global__ __launch_bounds__(256) void k_pcand_count(const PNode* nodes, const int32_t* inv, int32_t n_pleaf, uint32_t* cnt)
+{
+    const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (r <= n_pleaf) cnt[r] = r < n_pleaf ? (uint32_t)nodes[inv[r]].u.lf.nb_photons : 0u;
+}
+__global__ __launch_bounds__(256) void k_pcand_fill(const PNode* nodes, const PRange* pranges, const int32_t* inv, int32_t n_pleaf, const uint32_t* off, int32_t* out)
+{
+    // a wave per leaf: its ranges one after the other, a range's photons across the lanes
+    const int32_t wave = (int32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int32_t)(threadIdx.x & 63u), n_waves = (int32_t)((gridDim.x * blockDim.x) >> 6);
+    for (int32_t r = wave; r < n_pleaf; r += n_waves) {
+        const PNode& lf = nodes[inv[r]];
+        const PRange* ranges = pranges + lf.nb_off;
+        uint32_t at = off[r];
+        for (int32_t k = 0; k < lf.u.lf.nb_cnt; k++) {
+            const PRange rg = ranges[k];
+            for (int32_t j = lane; j < rg.count; j += 64) out[at + (uint32_t)j] = rg.first + j;
+            at += (uint32_t)rg.count;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_pdescent(const PNode* nodes, int32_t n, PDescent* out)
 {
     const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1120,6 +1142,7 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
             }
             continue;
         }
+        const uint32_t rank0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
         const PNode& lf = S.pnodes[leaf0];
         const int ncand = lf.u.lf.nb_photons;
         if constexpr (COUNT) { if (valid) n_c += (unsigned long long)ncand; }
@@ -1137,9 +1160,13 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
                 const int32_t m = min((int32_t)GI_GCHUNK, ncand - c0);
                 __builtin_amdgcn_wave_barrier();
                 if ((int32_t)lane < m) {
-                    int32_t off = c0 + (int32_t)lane, r = 0;
-                    while (off >= ranges[r].count) { off -= ranges[r].count; r++; }   // r < n_ranges: off < ncand = sum of the counts
-                    const size_t ph = (size_t)(ranges[r].first + off);
+                    size_t ph;
+                    if (S.pcand) ph = (size_t)S.pcand[S.pcand_off[rank0] + (uint32_t)(c0 + (int32_t)lane)];
+                    else {
+                        int32_t off = c0 + (int32_t)lane, r = 0;
+                        while (off >= ranges[r].count) { off -= ranges[r].count; r++; }   // r < n_ranges: off < ncand = sum of the counts
+                        ph = (size_t)(ranges[r].first + off);
+                    }
                     const double* pp = S.ph_pos + ph * 3;
                     cand[lane][0] = pp[0]; cand[lane][1] = pp[1]; cand[lane][2] = pp[2];
                     if (pass == 1) {
@@ -1225,6 +1252,125 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
         }
     }
     if constexpr (COUNT) { flush_u64(&sc->gather_queries, n_q); flush_u64(&sc->gather_cand, n_c); }
+}
+
+// A query per WAVE, for the passes with few queries.  Late passes hold a handful of queries per photon-map leaf: a wave of k_st_gather then either serves
+// sixty leaves one after the other with one or two lanes at work, or lets every lane walk its own leaf -- either way the pass lasts as long as some
+// five thousand candidate steps of one wave (1.2 - 1.6 ms on the benchmark frame, whatever the number of queries).  Here the lanes take a CANDIDATE
+// each: 64 keys per step, the 32 smallest kept across the lanes (a bitonic sort of the 64 new keys through lane exchanges, the smaller half against
+// the best so far, a bitonic merge: ~110 instructions per 64 candidates instead of 18 per candidate and query), tau read off lane K - 1; the second
+// pass computes every lane's contribution and adds those below tau in CANDIDATE ORDER (a lane at a time, read off by v_readlane), so the sums are the
+// sums of g_acc to the last bit; the tie group (keys equal to tau) likewise; float-key ties across rank 32 go to lane 0's gather_in_leaf, as everywhere.
+__device__ __forceinline__ double wave_read(double v, int src_lane)      // src_lane is wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ V3 gather_wave(const Scene& S, int32_t leaf, uint32_t rank, V3 pos, V3 dir, float* heap32, uint32_t lane, int* n_cand_out)
+{
+    const PNode& lf = S.pnodes[leaf];
+    const int ncand = lf.u.lf.nb_photons;
+    if (n_cand_out) *n_cand_out = ncand;
+    V3 res = v3(0, 0, 0);
+    if (ncand == 0) return res;
+    const int32_t* cand = S.pcand + S.pcand_off[rank];
+    const int K = ncand < GI_GATHER_K ? ncand : GI_GATHER_K;
+    // pass 1: the K-th smallest float key.  lane j < 32 holds the j-th smallest so far
+    float best = INFINITY;
+    for (int32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const int32_t c = c0 + (int32_t)lane;
+        float key = INFINITY;
+        if (c < ncand) {
+            const double* pp = S.ph_pos + (size_t)cand[c] * 3;
+            key = (float)len2(v3(pp[0], pp[1], pp[2]) - pos);            // the expression of g_key
+        }
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const float o = __shfl_xor(key, j);
+                const bool keep_min = ((lane & (uint32_t)j) == 0u) == ((lane & (uint32_t)k) == 0u);   // ascending blocks where bit k is clear (k = 64: everywhere)
+                key = keep_min ? fminf(key, o) : fmaxf(key, o);
+            }
+        const float r = __shfl(key, (int)((31u - lane) & 63u));         // the 32 smallest new keys, descending over lanes 0 .. 31
+        float m = lane < 32u ? fminf(best, r) : INFINITY;               // the 32 smallest of both, a bitonic sequence
+#pragma unroll
+        for (int j = 16; j > 0; j >>= 1) {
+            const float o = __shfl_xor(m, j);
+            m = (lane & (uint32_t)j) == 0u ? fminf(m, o) : fmaxf(m, o);
+        }
+        best = lane < 32u ? m : INFINITY;
+    }
+    const float tau = __shfl(best, K - 1);
+    // pass 2: g_acc over the candidates, in their order
+    V3 s_lt = v3(0, 0, 0), s_eq = v3(0, 0, 0);
+    int c_lt = 0, c_eq = 0;
+    double r_eq = 0;
+    for (int32_t c0 = 0; c0 < ncand; c0 += 64) {
+        const int32_t c = c0 + (int32_t)lane;
+        bool lt = false, eq = false;
+        double d2 = 0;
+        V3 contrib = v3(0, 0, 0);
+        if (c < ncand) {
+            const int32_t idx = cand[c];
+            const double* pp = S.ph_pos + (size_t)idx * 3;
+            d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
+            const float key = (float)d2;
+            lt = key < tau; eq = key == tau;
+            if (lt || eq) {
+                const double* dc = S.ph_dircol + (size_t)idx * 6;
+                contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
+            }
+        }
+        unsigned long long mlt = __ballot(lt), meq = __ballot(eq);
+        c_lt += (int)__popcll(mlt); c_eq += (int)__popcll(meq);
+        while (mlt != 0ull) {
+            const int b = __ffsll((long long)mlt) - 1;
+            mlt &= mlt - 1ull;
+            s_lt = s_lt + v3(wave_read(contrib.x, b), wave_read(contrib.y, b), wave_read(contrib.z, b));
+        }
+        while (meq != 0ull) {
+            const int b = __ffsll((long long)meq) - 1;
+            meq &= meq - 1ull;
+            s_eq = s_eq + v3(wave_read(contrib.x, b), wave_read(contrib.y, b), wave_read(contrib.z, b));
+            const double de = wave_read(d2, b);
+            r_eq = de > r_eq ? de : r_eq;
+        }
+    }
+    const int need = K - c_lt;       // g_end
+    if (c_eq > need) {               // float keys tie across rank 32: the exact pass, by one lane
+        if (lane == 0u) res = gather_in_leaf(S, leaf, pos, dir, heap32, 1, nullptr, nullptr);
+        res = v3(wave_read(res.x, 0), wave_read(res.y, 0), wave_read(res.z, 0));
+        return res;
+    }
+    return (s_lt + s_eq) / (GI_PI * r_eq);
+}
+#define GI_GW_BLOCK 256      // four waves: a wave per SIMD and workgroup, five workgroups per CU at 87 registers
+template <bool COUNT>
+__global__ __launch_bounds__(GI_GW_BLOCK) void k_st_gather_wave(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in,
+                                                            const unsigned long long* slot_sample, unsigned long long sample0, double* lbuf, StreamCounters* sc)
+{
+    __shared__ float heaps[(GI_GW_BLOCK / 64) * GI_GATHER_K];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long n_q = 0, n_c = 0;
+    for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; q < n_in; q += n_waves) {
+        const uint32_t rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[q]);
+        if constexpr (COUNT) n_q++;
+        if (rank >= (uint32_t)S.n_pleaf) continue;
+        const int32_t leaf = __builtin_amdgcn_readfirstlane(S.prank_leaf[rank]);
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)vals[q]);
+        const PathRec& p = pool[slot];
+        int nc = 0;
+        const V3 caustic = gather_wave(S, leaf, rank, ld3(p.hpos), ld3(p.gdir), heaps + wave * GI_GATHER_K, lane, &nc);
+        if constexpr (COUNT) n_c += (unsigned long long)nc;
+        if (lane == 0u && nc > 0) {
+            double* Lp = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance lives in the per-sample buffer
+            const V3 L = ld3(Lp) + ld3(p.gcoef) * caustic;
+            Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
+        }
+    }
+    if constexpr (COUNT) { if (lane != 0u) { n_q = 0; n_c = 0; } flush_u64(&sc->gather_queries, n_q); flush_u64(&sc->gather_cand, n_c); }
 }
 
 // the last stragglers of a chunk (paths bouncing between specular surfaces up to MAX_DEPTH), finished without one nearly
@@ -1501,6 +1647,10 @@ struct gi_ctx {
     DevBuf<float> d_cboxes;           // content boxes of the wide records' children
     DevBuf<uint32_t> d_cuse;
     bool cull_enabled = true;         // gi_set_content_culling
+    bool flat_candidates = true;      // GI_FLAT_CANDIDATES=0: k_st_gather finds a leaf's k-th candidate through its range list, no k_st_gather_wave
+    DevBuf<uint32_t> d_pcand_off;
+    DevBuf<int32_t> d_pcand;
+    uint32_t gather_wave_below = 200000u;    // GI_GATHER_WAVE_BELOW: gather passes with fewer queries give every query a wave (k_st_gather_wave)
     bool descent_jump = true;         // GI_DESCENT_JUMP=0: the fast descent of the gather keys starts at the root
     DevBuf<int32_t> d_pjump;          // its jump table (gi_device.h: gather_find_leaf_fast)
     DevBuf<double> d_pjump_aux;
@@ -1603,11 +1753,12 @@ int fail(gi_ctx* c, int code, const std::string& msg)
 
 }  // namespace
 
+__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* ghist, uint32_t total);   // gi_sort.inc
 // the sort key of the gather queries (k_pleaf_rank), for the photon tables c->S points at
 static int install_pleaf_rank(gi_ctx* c)
 {
     Scene& S = c->S;
-    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0; S.pdescent = nullptr; S.pjump = nullptr;
+    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0; S.pdescent = nullptr; S.pjump = nullptr; S.pcand_off = nullptr; S.pcand = nullptr;
     if (S.n_pnode <= 0) return GI_OK;
     if (c->d_pleaf_rank.n < (size_t)S.n_pnode) { HIP_TRY(c, c->d_pleaf_rank.alloc((size_t)S.n_pnode)); HIP_TRY(c, c->d_prank_leaf.alloc((size_t)S.n_pnode)); }
     if (!c->d_n_pleaf.p) HIP_TRY(c, c->d_n_pleaf.alloc(1));
@@ -1617,6 +1768,22 @@ static int install_pleaf_rank(gi_ctx* c)
     HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_pleaf.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     S.pleaf_rank = c->d_pleaf_rank.p; S.prank_leaf = c->d_prank_leaf.p; S.n_pleaf = n;
+    S.pcand_off = nullptr; S.pcand = nullptr;
+    if (c->flat_candidates && n > 0) {
+        if (c->d_pcand_off.n < (size_t)n + 1) HIP_TRY(c, c->d_pcand_off.alloc((size_t)n + 1));
+        hipLaunchKernelGGL(k_pcand_count, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, S.pnodes, c->d_prank_leaf.p, n, c->d_pcand_off.p);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, c->stream, c->d_pcand_off.p, (uint32_t)n + 1u);
+        HIP_TRY(c, hipGetLastError());
+        uint32_t total = 0;
+        HIP_TRY(c, hipMemcpyAsync(&total, c->d_pcand_off.p + n, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (total > 0 && total < 0x7fffffffu) {
+            if (c->d_pcand.n < (size_t)total) HIP_TRY(c, c->d_pcand.alloc((size_t)total));
+            hipLaunchKernelGGL(k_pcand_fill, dim3(1024), dim3(256), 0, c->stream, S.pnodes, S.pranges, c->d_prank_leaf.p, n, c->d_pcand_off.p, c->d_pcand.p);
+            HIP_TRY(c, hipGetLastError());
+            S.pcand_off = c->d_pcand_off.p; S.pcand = c->d_pcand.p;
+        }
+    }
     // the split records of the descent and the map's own box (gather_find_leaf_fast); the one-record-per-level layout only (children from the parent's planes)
     if (c->fast_descent && S.pn_planes) {
         if (c->d_pdescent.n < (size_t)S.n_pnode) HIP_TRY(c, c->d_pdescent.alloc((size_t)S.n_pnode));
@@ -1681,6 +1848,8 @@ int gi_create(gi_ctx** out, int device_ordinal)
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
     if (const char* e = getenv("GI_DESCENT_JUMP")) c->descent_jump = atoi(e) != 0;
+    if (const char* e = getenv("GI_FLAT_CANDIDATES")) c->flat_candidates = atoi(e) != 0;
+    if (const char* e = getenv("GI_GATHER_WAVE_BELOW")) c->gather_wave_below = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("GI_SORT_SHADE")) c->sort_shade = atoi(e) != 0;
     if (const char* e = getenv("GI_SORT_SHADE_LO")) c->sort_shade_lo = std::max(0, atoi(e));
     if (const char* e = getenv("GI_SORT_LO_BIT")) c->sort_lo_bit = std::min(26, std::max(0, atoi(e)));
@@ -2137,7 +2306,12 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
                 if (rc) return rc;
             }
             stage_end(c);
-            stage_begin(c, STG_GATHER); hipLaunchKernelGGL(counting ? (k_st_gather<true>) : (k_st_gather<false>), dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf, sc); stage_end(c);
+            stage_begin(c, STG_GATHER);
+            if (c->S.pcand && n_gather < c->gather_wave_below)      // few queries: a wave each
+                hipLaunchKernelGGL(counting ? (k_st_gather_wave<true>) : (k_st_gather_wave<false>), dim3(std::min<uint32_t>((uint32_t)(5 * c->n_cu), (n_gather + 3u) / 4u)), dim3(GI_GW_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf, sc);
+            else
+                hipLaunchKernelGGL(counting ? (k_st_gather<true>) : (k_st_gather<false>), dim3(G.gather), dim3(GI_BLOCK), 0, st, c->S, pool, c->d_gk[1].p, c->d_gv[1].p, n_gather, c->d_slot_sample.p, sample0, lbuf, sc);
+            stage_end(c);
             launches += 2;
         }
         n_cont = c->h_ctl->n_cont;
