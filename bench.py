@@ -128,7 +128,8 @@ def _sum_family(per_kernel, family, field):
     """Sum a counter over the instances of one kernel family ('k_st_trace' matches 'k_st_trace<0, 1, false>')."""
     tot, hit = 0.0, False
     for name, d in per_kernel.items():
-        if name.split("<")[0] == family and field(d) is not None:
+        base = name.split("<")[0].replace("void ", "")
+        if (base == family or base.startswith(family + "_")) and field(d) is not None:     # k_st_gather_wave belongs to k_st_gather
             tot += field(d)
             hit = True
     return tot if hit else None

@@ -1421,7 +1421,20 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
             for (int b = 0;;) {
                 if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; break; }
                 const int fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
-                if (fl & ST_GATHER) stage_gather(S, p, heap, heap_stride, nullptr);
+                if (fl & ST_GATHER) {
+                    if (MODE == 1 && S.pcand) {   // the wave carries ONE path: its lanes take a candidate each (gather_wave: the sums of gather_in_leaf to the last bit)
+                        const V3 gp = ld3(p.hpos);
+                        const int32_t leaf = gather_find_leaf(S, gp);
+                        V3 caustic = v3(0, 0, 0);
+                        if (leaf >= 0) {
+                            const int32_t rank = S.pleaf_rank[leaf];
+                            if (rank >= 0) caustic = gather_wave(S, leaf, (uint32_t)rank, gp, ld3(p.gdir), reinterpret_cast<float*>(gi_dyn_lds + GI_FINISH_COOP_HEAP_OFF) + (threadIdx.x >> 6) * GI_GATHER_K, lane, nullptr);
+                        }
+                        const V3 L = ld3(p.L) + ld3(p.gcoef) * caustic;      // stage_gather
+                        p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+                    } else
+                        stage_gather(S, p, heap, heap_stride, nullptr);
+                }
                 if (!(fl & ST_CONTINUE)) { alive = false; break; }
                 if (++b >= max_bounces) break;
             }

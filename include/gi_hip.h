@@ -138,7 +138,10 @@ int gi_set_wide_nodes(gi_ctx*, int enable);
 int gi_set_content_culling(gi_ctx*, int enable);
 /* Entity boxes: 1 (default) = the wide walk runs Entity::intersect only on the references of a leaf whose own (widened) box the ray touches; 0 = on
  * every reference, as RayTracer::trace / visible do (include/raytracer.h:290-305,446-472).  A ray that misses an entity's box cannot hit the entity:
- * same hits, same order, same frame bit for bit; exists so that the two can be compared.  Returns 1 when in use after the call.                  */
+ * same hits, same order, same frame bit for bit; exists so that the two can be compared.  Returns 1 when in use after the call.
+ * The closest-hit walk's further cuts hang on the same switch (0 = off, the walks ask exactly what the reference asks): boxes cut to the part of an
+ * opaque entity inside its leaf, content boxes made of those, no look behind the best hit -- and with them the re-walk of a ray that met two
+ * entities at exactly the same distance, and the plain walk of rays along an axis plane (gi_device.h: trace_wide_step).       */
 int gi_set_entity_boxes(gi_ctx*, int enable);
 /* Upper bound on paths in flight in the wavefront pipeline (224 B each).  Default: as many as 80 % of the free HBM holds,
  * up to the whole frame (1080p x 256 spp = 531 M paths = 119 GB).                                                           */

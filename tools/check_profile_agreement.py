@@ -10,7 +10,7 @@ frames = d["steps"] + d["warmup"]
 tot, parts = 0.0, {}
 for r in rows:
     n = r["Name"]
-    if n.startswith("k_emit") or n.startswith("k_pb_") or n.startswith("k_pleaf") or "at::native" in n:      # photon emission / map build (setup) and torch's own fills are not part of a frame
+    if n.startswith(("k_emit", "k_pb_", "k_pleaf", "k_pcand", "k_pjump", "k_pdescent")) or "at::native" in n:      # photon emission / map build (setup) and torch's own fills are not part of a frame
         continue
     t = float(r["TotalDurationNs"]) / 1e6 / frames
     tot += t
@@ -21,7 +21,7 @@ pipeline_ms = roof.get("pipeline_ms", roof["kernel_ms"])
 print("rocprof kernel durations per frame: %.1f ms; bench.py HIP events: %.1f ms (ratio %.4f)" % (tot, pipeline_ms, tot / pipeline_ms))
 stages = roof["stage_ms"]
 name = max(stages, key=stages.get)                        # the dominant stage (trace / shade / shadow / gather: one kernel each)
-k = [v for n, v in parts.items() if n.split("<")[0] == "k_st_" + name or (name == "shade" and "shadow" not in stages and n.startswith("k_st_shadow"))]
+k = [v for n, v in parts.items() if n.split("<")[0].split("(")[0] in ("k_st_" + name, "k_st_" + name + "_wave") or (name == "shade" and "shadow" not in stages and n.startswith("k_st_shadow"))]
 print("dominant k_st_%s: rocprof %.1f ms, bench.py %.1f ms" % (name, sum(k), stages[name]))
 if "per_kernel" in roof:
     # the counter summaries the line says it used (relative to the repository root), else this tag's
@@ -32,7 +32,8 @@ if "per_kernel" in roof:
     print("counters: %s, %s" % (os.path.relpath(sq_path, root), os.path.relpath(hb_path, root)))
     sq = json.load(open(sq_path))["per_kernel"]
     hb = json.load(open(hb_path))["per_kernel"]
-    fam = lambda table, f, get: sum(get(v) for n, v in table.items() if n.split("<")[0] == f and get(v) is not None)
+    base = lambda n: n.split("<")[0].replace("void ", "")
+    fam = lambda table, f, get: sum(get(v) for n, v in table.items() if (base(n) == f or base(n).startswith(f + "_")) and get(v) is not None)
     bad = 0
     for f, e in roof["per_kernel"].items():
         ms = e["ms_per_frame"]
