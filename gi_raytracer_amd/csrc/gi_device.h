@@ -1746,7 +1746,8 @@ struct alignas(16) PathRec {    // 224 B, one per path in flight (HBM-resident i
 static_assert(sizeof(PathRec) == 224, "PathRec layout");
 enum { ST_CONTINUE = 1, ST_GATHER = 2 };
 
-GI_HD void path_begin_lean(PathRec& p, const Ray& ray, uint32_t sample)   // one 64-byte store: what a depth-0 path consists of
+template <class P>
+GI_HD void path_begin_lean(P& p, const Ray& ray, uint32_t sample)   // one 64-byte store: what a depth-0 path consists of (P: PathRec, or the streaming pool's PathRef)
 {
     p.o[0] = ray.o.x; p.o[1] = ray.o.y; p.o[2] = ray.o.z;
     p.d[0] = ray.d.x; p.d[1] = ray.d.y; p.d[2] = ray.d.z;
@@ -1817,8 +1818,8 @@ struct ShadowQ { double o[3], dir[3], A[3]; uint32_t idx, stream; int32_t depth;
 // Lext: where the path's radiance accumulates when it does not live in the record (streaming pipeline: the per-sample radiance buffer,
 // so that a path that ends -- 96 % of the benchmark's reflected rays leave the scene -- has nothing left to read or write); else p.L.
 // DEFER (1: scenes with one light, 2: with several): the shadow walks are put off (sq), this function then contains no walk and touches no radiance at all.
-template <int FEAT, class Nodes, int DEFER = 0>
-GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, PathRec& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr, double* Lext = nullptr, ShadowQ* sq = nullptr)
+template <int FEAT, class Nodes, int DEFER = 0, class P = PathRec>
+GI_HD int stage_shade_nodes(const Scene& S, const Nodes& N, P& p, uint64_t seed, Counters* c, ShadeOut* so = nullptr, double* Lext = nullptr, ShadowQ* sq = nullptr)
 {
     double* const Lp = Lext ? Lext : p.L;
     Rng rng = rng_make(seed, p.stream);
@@ -1948,7 +1949,8 @@ GI_HD int stage_shade(const Scene& S, PathRec& p, uint64_t seed, Counters* c)
     return S.n_tex > 0 ? stage_shade_nodes<7>(S, N, p, seed, c) : stage_shade_nodes<3>(S, N, p, seed, c);
 }
 // stage 3: the caustic term of the vertex just shaded: L += (T*color) * samplePhotons(hit, refDir, 32)
-GI_HD void stage_gather_in_leaf(const Scene& S, PathRec& p, int32_t leaf, float* heap_mem, int heap_stride, double* Lext = nullptr)
+template <class P>
+GI_HD void stage_gather_in_leaf(const Scene& S, P& p, int32_t leaf, float* heap_mem, int heap_stride, double* Lext = nullptr)
 {
     double* const Lp = Lext ? Lext : p.L;
     V3 caustic = gather_in_leaf(S, leaf, ld3(p.hpos), ld3(p.gdir), heap_mem, heap_stride, nullptr, nullptr);

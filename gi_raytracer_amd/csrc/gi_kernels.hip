@@ -245,6 +245,59 @@ __device__ __forceinline__ void flush_walk_cnt(unsigned long long* dst6, const W
 // each kernel working on a compacted queue of slot indices (appended with one atomic per wave from a ballot), so that all
 // 64 lanes of a wave run the same stage; k_wf_accum then folds the finished paths into the per-pixel running mean in sample
 // order.  Per-path arithmetic is the same stage_* code the megakernel runs, so both give the same numbers.
+// The streaming pipeline's paths in flight: ONE ARRAY PER GROUP OF FIELDS that a stage reads or writes together, instead of one 224-byte PathRec per
+// path.  A stage wants 40 - 160 bytes of a path; out of records it moved whole DRAM pages for them (exp/aos_bench.hip: the shade stage's
+// read-104-write-172 pattern costs 48 ms per 477 M records as 224-byte structures, 24 ms as field arrays).  pool[slot] gives a PathRef -- the field
+// names of PathRec as references -- so the stage functions (templates on the path type) read and write exactly the fields they did.
+struct PoolRay  { double o[3], d[3]; uint32_t stream; int32_t depth; uint32_t pad_[2]; };   // 64 B: all a new path consists of, all the trace stage reads
+struct PoolHit  { double hpos[3], hu, hv; int32_t htri; uint32_t mf; };                     // 48 B: what the trace stage leaves for the shade stage
+struct PoolThru { double T[3], contrib[3]; };                                               // 48 B
+struct PoolGath { double gdir[3], gcoef[3]; };                                              // 48 B: the pending photon gather (and minUV between trace and shade)
+struct PathRef {
+    double (&o)[3]; double (&d)[3]; uint32_t& stream; int32_t& depth; int32_t& htri; uint32_t& pad;
+    double (&T)[3]; double (&contrib)[3]; double (&gdir)[3]; double (&gcoef)[3]; double (&hpos)[3]; double& hu; double& hv; double (&L)[3];
+};
+#define GI_POOL_BYTES_PER_SLOT (sizeof(PoolRay) + sizeof(PoolHit) + sizeof(PoolThru) + sizeof(PoolGath) + 24)
+struct PathPool {
+    PoolRay* ray; PoolHit* hit; PoolThru* thru; PoolGath* gath; double* L;
+    __device__ __forceinline__ PathRef operator[](size_t s) const
+    {
+        return PathRef{ray[s].o, ray[s].d, ray[s].stream, ray[s].depth, hit[s].htri, hit[s].mf, thru[s].T, thru[s].contrib, gath[s].gdir, gath[s].gcoef,
+                       hit[s].hpos, hit[s].hu, hit[s].hv, *reinterpret_cast<double (*)[3]>(L + s * 3)};
+    }
+    __device__ __forceinline__ PathRec load(size_t s) const     // a copy in registers (finisher)
+    {
+        PathRec p;
+        const PathRef r = (*this)[s];
+        for (int k = 0; k < 3; k++) { p.o[k] = r.o[k]; p.d[k] = r.d[k]; p.T[k] = r.T[k]; p.contrib[k] = r.contrib[k]; p.gdir[k] = r.gdir[k]; p.gcoef[k] = r.gcoef[k]; p.hpos[k] = r.hpos[k]; p.L[k] = r.L[k]; }
+        p.stream = r.stream; p.depth = r.depth; p.htri = r.htri; p.pad = r.pad; p.hu = r.hu; p.hv = r.hv;
+        return p;
+    }
+    __device__ __forceinline__ void store(size_t s, const PathRec& p) const
+    {
+        const PathRef r = (*this)[s];
+        for (int k = 0; k < 3; k++) { r.o[k] = p.o[k]; r.d[k] = p.d[k]; r.T[k] = p.T[k]; r.contrib[k] = p.contrib[k]; r.gdir[k] = p.gdir[k]; r.gcoef[k] = p.gcoef[k]; r.hpos[k] = p.hpos[k]; r.L[k] = p.L[k]; }
+        r.stream = p.stream; r.depth = p.depth; r.htri = p.htri; r.pad = p.pad; r.hu = p.hu; r.hv = p.hv;
+    }
+};
+__device__ __forceinline__ void pool_begin(const PathPool& pool, size_t slot, const Ray& ray, uint32_t sample)   // a new path: one 64-byte store (path_begin_lean)
+{
+    PoolRay& r = pool.ray[slot];
+    r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z;
+    r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z;
+    r.stream = sample; r.depth = 0; r.pad_[0] = 0u; r.pad_[1] = 0u;
+}
+static PathPool make_path_pool(void* base, size_t n)
+{
+    PathPool P;
+    char* b = static_cast<char*>(base);
+    P.ray = reinterpret_cast<PoolRay*>(b); b += n * sizeof(PoolRay);
+    P.hit = reinterpret_cast<PoolHit*>(b); b += n * sizeof(PoolHit);
+    P.thru = reinterpret_cast<PoolThru*>(b); b += n * sizeof(PoolThru);
+    P.gath = reinterpret_cast<PoolGath*>(b); b += n * sizeof(PoolGath);
+    P.L = reinterpret_cast<double*>(b);
+    return P;
+}
 struct PixRec { double color[3], lastCol[3], var; int32_t samps, s, n, pad; };
 
 __device__ __forceinline__ uint32_t wave_append(unsigned int* counter, bool pred)
@@ -410,7 +463,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_wf_accum(Frame F, PixRec* pix, con
 // Adaptive rounds on the streaming machinery (render_adaptive): the paths of a round are started here, compacted into q_new, and then
 // go through the k_st_* passes; a finished path leaves its radiance in lbuf[slot] (slot_sample[slot] = slot), which the accumulate
 // step folds into the pixel in sample order.
-__global__ __launch_bounds__(GI_BLOCK) void k_ad_gen(Scene S, Frame F, PixRec* pix, PathRec* pool, unsigned long long* slot_sample, uint32_t n_pix, int B,
+__global__ __launch_bounds__(GI_BLOCK) void k_ad_gen(Scene S, Frame F, PixRec* pix, PathPool pool, unsigned long long* slot_sample, uint32_t n_pix, int B,
                                                     uint32_t* q_new, unsigned int* n_new)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -442,7 +495,7 @@ __global__ __launch_bounds__(GI_BLOCK) void k_ad_gen(Scene S, Frame F, PixRec* p
             if (start) {
                 uint32_t idx;
                 Ray ray = primary_ray(S, F, s0 + k, x, y, idx);
-                path_begin_lean(pool[slot], ray, idx);
+                pool_begin(pool, slot, ray, idx);
                 slot_sample[slot] = slot;
             }
             const uint32_t at = wave_append(n_new, start);
@@ -556,7 +609,7 @@ struct GenArgs {
 // of the lanes were active per leaf step).  Waves of new paths (neighbouring pixels, leaves shared through the scalar cache) stay in
 // lockstep: refill_min = 64 for them.  The workgroup's items are those of the grid-stride loop, so seg_start still bounds its output.
 template <int FEAT, int WIDE, bool COUNT = false>
-__global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathRec* pool, unsigned long long* slot_sample, unsigned long long sample0,
+__global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t seed, PathPool pool, unsigned long long* slot_sample, unsigned long long sample0,
                                                        GenArgs g, const uint32_t* q_a, uint32_t n_a, const uint32_t* q_b, uint32_t n_b, unsigned int* bc, uint32_t* segs,
                                                        uint32_t* q_shade, uint32_t* q_free, double* lbuf, uint32_t refill_min, StreamCounters* sc)
 {
@@ -587,7 +640,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
             depth = 0;
         } else {
             slot = i - g.n_gen < n_a ? q_a[i - g.n_gen] : q_b[i - g.n_gen - n_a];
-            const PathRec& p = pool[slot];
+            const PoolRay& p = pool.ray[slot];
             ray = make_ray_exact(ld3(p.o), ld3(p.d));
             stream = p.stream; depth = p.depth;
         }
@@ -595,9 +648,9 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
     // what a finished walk leaves behind: the hit in the record (a new path's record is created here), or the end of the path
     auto retire = [&](uint32_t i, uint32_t slot, const Ray& ray, uint32_t stream, int32_t depth, bool hit, const HitRec& h) {
         const bool gen = i < g.n_gen;
-        PathRec& p = pool[slot];
         if (hit) {
-            if (gen) { path_begin_lean(p, ray, stream); slot_sample[slot] = g.id_base + i; }
+            PoolHit& p = pool.hit[slot];
+            if (gen) { pool_begin(pool, slot, ray, stream); slot_sample[slot] = g.id_base + i; }
             if constexpr (WIDE != 0) {
                 // the walk carries only WHICH entity it hit: hit point and barycentrics are computed again here, by the same test with the same
                 // operands -- ten registers less to hold through the walk (the kernel runs at the 128 its four waves per SIMD leave it)
@@ -607,12 +660,12 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                 const uint32_t mf = ((uint32_t)tg.mat << 3) | tg.flags;      // = LeafTri::matflags of every reference to it
                 ent_hit<FEAT>(tg, mf, ray, ru, rv, rp);
                 p.hpos[0] = rp.x; p.hpos[1] = rp.y; p.hpos[2] = rp.z;
-                p.hu = ru; p.hv = rv; p.htri = h.tri; p.pad = mf;
+                p.hu = ru; p.hv = rv; p.htri = h.tri; p.mf = mf;
             } else {
             p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
-            p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.pad = h.mf;
+            p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.mf = h.mf;
             }
-            if (FEAT & GI_FEAT_TEX) { p.gdir[0] = h.tu; p.gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
+            if (FEAT & GI_FEAT_TEX) { pool.gath[slot].gdir[0] = h.tu; pool.gath[slot].gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
         } else if (depth <= GI_MAX_DEPTH) {
             // the path ends here with a miss: L += T * ambient (stage_trace_nodes), on the per-sample radiance buffer where the path's L lives.
             // A path at depth 0 writes (L = 0, T = 1 by definition); a deeper one adds -- and when the scene has no ambient light there is nothing
@@ -626,7 +679,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
                 o[0] = L.x; o[1] = L.y; o[2] = L.z;
             } else if (amb.x != 0.0 || amb.y != 0.0 || amb.z != 0.0) {
                 double* o = lbuf + (slot_sample[slot] - sample0) * 3;
-                const V3 L = ld3(o) + ld3(p.T) * amb;
+                const V3 L = ld3(o) + ld3(pool.thru[slot].T) * amb;
                 o[0] = L.x; o[1] = L.y; o[2] = L.z;
             }
         }
@@ -723,7 +776,7 @@ __global__ void k_iota(uint32_t* v, uint32_t n) { for (uint32_t i = blockIdx.x *
 #define GI_DEFER_WAVES 2
 #endif
 template <int FEAT, int WIDE, int DEFER>
-__global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_st_shade(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+__global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_st_shade(Scene S, uint64_t seed, PathPool pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                        const uint32_t* q_shade, const StreamCtl* ctl, unsigned int* bc, uint32_t* segs, uint32_t* q_cont, uint32_t* k_cont, uint32_t* q_gather, double* g_pos,
                                                        uint32_t* q_free, double* lbuf, ShadowQ* shq, const uint32_t* q_orig)
 {
@@ -762,13 +815,14 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
         so.key = 0; so.gpos = v3(0, 0, 0);
         if (valid) {
             slot = q_shade[i];
+            PathRef pr = pool[slot];
             if constexpr (DEFER != 0) {
                 const int nl = DEFER == 2 ? S.n_light : 1;          // one query per light, the queries of item i side by side
                 ShadowQ* const e = shq + (size_t)(q_orig ? q_orig[i] : i) * (size_t)nl;   // q_orig: the item's place in the queue the shadow kernel follows (the trace stage's order)
-                fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, pool[slot], seed, nullptr, &so, nullptr, e);
+                fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, pr, seed, nullptr, &so, nullptr, e);
                 for (int li = 0; li < nl; li++) { e[li].idx = (uint32_t)(slot_sample[slot] - sample0); e[li].slot = slot; }
             } else
-                fl = stage_shade_nodes<FEAT>(S, N, pool[slot], seed, nullptr, &so, lbuf + (slot_sample[slot] - sample0) * 3);
+                fl = stage_shade_nodes<FEAT>(S, N, pr, seed, nullptr, &so, lbuf + (slot_sample[slot] - sample0) * 3);
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
@@ -795,7 +849,7 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
 // MULTI: several lights -- the reference keeps the share of the LAST visible light of a vertex, so a lane asks the item's queries from the last light
 // down and stops at the first visible one (the medium's answer is then needed at the end of each walk, not only when the lane retires).
 template <int FEAT, int MULTI, bool COUNT = false>
-__global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t seed, const PathRec* pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min, StreamCounters* sc)
+__global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t seed, PathPool pool, const ShadowQ* shq, const StreamCtl* ctl, double* lbuf, uint32_t refill_min, StreamCounters* sc)
 {
     const uint32_t nl = MULTI ? (uint32_t)S.n_light : 1u;
     uint32_t li = 0;   // the light this lane's walk is about
@@ -828,7 +882,7 @@ __global__ __launch_bounds__(GI_SHADOW_BLOCK) void k_st_shadow(Scene S, uint64_t
                 if (e.depth == 0 || vis || e0.live == 2u) {
                     // L += T * (color * i + emissive): i = the light's share when it is visible (A), else 0 (A0: zero unless the surface emits,
                     // and then L + 0 = L is not worth a write -- except at depth 0, where L = 0 + ... starts the sum)
-                    const V3 add = vis ? ld3(e.A) : (e0.live == 2u ? ld3(pool[e.slot].L) : v3(0, 0, 0));
+                    const V3 add = vis ? ld3(e.A) : (e0.live == 2u ? ld3(pool.L + (size_t)e.slot * 3) : v3(0, 0, 0));
                     const V3 L = (e.depth == 0 ? v3(0, 0, 0) : ld3(o)) + add;
                     o[0] = L.x; o[1] = L.y; o[2] = L.z;
                 }
@@ -1106,7 +1160,7 @@ __device__ __forceinline__ void kmerge32(float (&v)[32])   // bitonic sequence -
         }
 }
 template <bool COUNT>
-__global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in,
+__global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S, PathPool pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in,
                                                                          const unsigned long long* slot_sample, unsigned long long sample0, double* lbuf, StreamCounters* sc)
 {
     unsigned long long n_q = 0, n_c = 0;   // COUNT: queries of this lane, candidates they scanned (a leaf's whole candidate list per query, as PhotonMap::getInRange returns it)
@@ -1138,7 +1192,8 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
         if (!uniform) {
             if (has_leaf) {
                 if constexpr (COUNT) n_c += (unsigned long long)S.pnodes[leaf].u.lf.nb_photons;
-                stage_gather_in_leaf(S, pool[vals[i]], (int32_t)leaf, heap, 64, lbuf + (slot_sample[vals[i]] - sample0) * 3);
+                PathRef pr = pool[vals[i]];
+                stage_gather_in_leaf(S, pr, (int32_t)leaf, heap, 64, lbuf + (slot_sample[vals[i]] - sample0) * 3);
             }
             continue;
         }
@@ -1149,8 +1204,8 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
         if (ncand == 0) continue;
         const PRange* ranges = S.pranges + lf.nb_off;
         GatherAcc a;
-        PathRec* p = valid ? &pool[vals[i]] : nullptr;
-        g_begin(a, valid ? ld3(p->hpos) : v3(0, 0, 0), valid ? ld3(p->gdir) : v3(0, 0, 0), heap, 64, ncand);
+        const uint32_t gslot = valid ? vals[i] : 0u;
+        g_begin(a, valid ? ld3(pool.hit[gslot].hpos) : v3(0, 0, 0), valid ? ld3(pool.gath[gslot].gdir) : v3(0, 0, 0), heap, 64, ncand);
         float best[32];
 #pragma unroll
         for (int k = 0; k < 32; k++) best[k] = INFINITY;
@@ -1247,7 +1302,7 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
             V3 caustic;
             if (!g_end(a, caustic)) caustic = gather_in_leaf(S, (int32_t)leaf0, a.pos, a.dir, heap, 64, nullptr, nullptr);   // float-key tie: exact pass
             double* Lp = lbuf + (slot_sample[vals[i]] - sample0) * 3;   // the path's radiance lives in the per-sample buffer
-            V3 L = ld3(Lp) + ld3(p->gcoef) * caustic;
+            V3 L = ld3(Lp) + ld3(pool.gath[gslot].gcoef) * caustic;
             Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
         }
     }
@@ -1347,7 +1402,7 @@ __device__ __forceinline__ V3 gather_wave(const Scene& S, int32_t leaf, uint32_t
 }
 #define GI_GW_BLOCK 256      // four waves: a wave per SIMD and workgroup, five workgroups per CU at 87 registers
 template <bool COUNT>
-__global__ __launch_bounds__(GI_GW_BLOCK) void k_st_gather_wave(Scene S, PathRec* pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in,
+__global__ __launch_bounds__(GI_GW_BLOCK) void k_st_gather_wave(Scene S, PathPool pool, const uint32_t* keys, const uint32_t* vals, uint32_t n_in,
                                                             const unsigned long long* slot_sample, unsigned long long sample0, double* lbuf, StreamCounters* sc)
 {
     __shared__ float heaps[(GI_GW_BLOCK / 64) * GI_GATHER_K];
@@ -1360,13 +1415,12 @@ __global__ __launch_bounds__(GI_GW_BLOCK) void k_st_gather_wave(Scene S, PathRec
         if (rank >= (uint32_t)S.n_pleaf) continue;
         const int32_t leaf = __builtin_amdgcn_readfirstlane(S.prank_leaf[rank]);
         const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)vals[q]);
-        const PathRec& p = pool[slot];
         int nc = 0;
-        const V3 caustic = gather_wave(S, leaf, rank, ld3(p.hpos), ld3(p.gdir), heaps + wave * GI_GATHER_K, lane, &nc);
+        const V3 caustic = gather_wave(S, leaf, rank, ld3(pool.hit[slot].hpos), ld3(pool.gath[slot].gdir), heaps + wave * GI_GATHER_K, lane, &nc);
         if constexpr (COUNT) n_c += (unsigned long long)nc;
         if (lane == 0u && nc > 0) {
             double* Lp = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance lives in the per-sample buffer
-            const V3 L = ld3(Lp) + ld3(p.gcoef) * caustic;
+            const V3 L = ld3(Lp) + ld3(pool.gath[slot].gcoef) * caustic;
             Lp[0] = L.x; Lp[1] = L.y; Lp[2] = L.z;
         }
     }
@@ -1395,7 +1449,7 @@ __device__ __forceinline__ int finish_mode(int wide, int lanes, uint32_t n_in, u
     return 0;
 }
 template <int FEAT, int WIDE, int MODE>
-__global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathRec* pool, const unsigned long long* slot_sample, unsigned long long sample0,
+__global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t seed, PathPool pool, const unsigned long long* slot_sample, unsigned long long sample0,
                                                         const uint32_t* q_in, const unsigned int* n_in_dev, uint32_t n_in_host, int lanes, int max_bounces,
                                                         uint32_t* q_out, unsigned int* n_out, double* lbuf, uint32_t coop_factor)
 {
@@ -1414,7 +1468,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
         const uint32_t grp = lane / G;
         for (uint32_t i = wave * per_wave + grp; i < n_in; i += n_waves * per_wave) {
             const uint32_t slot = q_in[i];
-            PathRec p = pool[slot];
+            PathRec p = pool.load(slot);
             double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance so far; kept in registers while this stage works on it
             p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
             bool alive = true;
@@ -1441,7 +1495,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
             if ((lane & (G - 1u)) == 0u) {
                 Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
                 if (alive) {
-                    pool[slot] = p;
+                    pool.store(slot, p);
                     q_out[atomicAdd(n_out, 1u)] = slot;
                 }
             }
@@ -1453,7 +1507,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
         if (lane >= (uint32_t)lanes) return;
         for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
             const uint32_t slot = q_in[i];
-            PathRec p = pool[slot];
+            PathRec p = pool.load(slot);
             double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;
             p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
             bool alive = true;
@@ -1466,7 +1520,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
             }
             Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
             if (alive) {
-                pool[slot] = p;
+                pool.store(slot, p);
                 q_out[atomicAdd(n_out, 1u)] = slot;
             }
         }
@@ -1704,7 +1758,9 @@ struct gi_ctx {
     DevBuf<unsigned int> d_tile_counter;
     DevBuf<Counters> d_counters;
     // wavefront pipeline workspaces (grown on demand, kept between frames)
-    DevBuf<PathRec> d_pool;
+    DevBuf<PathRec> d_pool;               // paths of the round-based wavefront pipeline (records)
+    DevBuf<unsigned char> d_spool;        // paths of the streaming pipeline: field arrays (PathPool), GI_POOL_BYTES_PER_SLOT each
+    size_t spool_slots = 0;
     DevBuf<PixRec> d_pix;
     DevBuf<uint32_t> d_q[4];          // trace ping, trace pong, shade, gather
     DevBuf<unsigned int> d_wfcnt;     // [0] shade, [1] next, [2] gather, [3] pixels still wanting samples
@@ -2150,7 +2206,7 @@ static const StreamGrids& stream_grids(gi_ctx* c)   // per context: one process 
 static bool defers_shadows(const gi_ctx* c) { return c->defer_shadows && c->S.wnodes != nullptr && c->S.n_light >= 1 && c->S.n_light <= 4; }   // one query per light and shaded hit
 static int stream_alloc(gi_ctx* c, uint32_t P)
 {
-    if (c->d_pool.n < P) HIP_TRY(c, c->d_pool.alloc(P));
+    if (c->spool_slots < P) { HIP_TRY(c, c->d_spool.alloc((size_t)P * GI_POOL_BYTES_PER_SLOT)); c->spool_slots = P; }
     if (c->d_slot_sample.n < P) HIP_TRY(c, c->d_slot_sample.alloc(P));
     for (int k = 0; k < 6; k++) if (c->d_qs[k].n < P) HIP_TRY(c, c->d_qs[k].alloc(P));
     if (c->d_q[0].n < P) HIP_TRY(c, c->d_q[0].alloc(P));
@@ -2187,7 +2243,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
     const bool counting = c->count_stream;
     if (counting && !(wide && defers_shadows(c) && !c->S.has_spheres && c->S.n_fog == 0 && c->S.n_tex == 0))
         return fail(c, GI_E_STATE, "render: the streaming work counters (gi_set_counters 2) cover triangle scenes without spheres, fog or textures, walked over wide records with one to four lights; use mode 1 (reference visits, megakernel) for this scene");
-    PathRec* pool = c->d_pool.p;
+    const PathPool pool = make_path_pool(c->d_spool.p, c->spool_slots);
     StreamCtl* ctl = c->d_ctl.p;
     uint32_t* q_new = c->d_qs[0].p;
     uint32_t* q_cont[2] = {c->d_qs[1].p, c->d_qs[2].p};
@@ -2260,9 +2316,9 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
         const uint32_t* q_orig = nullptr;
         if (c->sort_shade && n_cont > 0) {
             int sbits = 1;
-            while ((1ull << sbits) < (unsigned long long)c->d_pool.n) sbits++;
+            while ((1ull << sbits) < (unsigned long long)c->spool_slots) sbits++;
             uint32_t* const tk = reinterpret_cast<uint32_t*>(c->d_sort_tmp.p);
-            const uint32_t bound = n_prepared + n_cont;
+            const uint32_t bound = n_new + n_cont;      // every item of the trace stage may have hit something
             stage_begin(c, STG_SORT);
             hipLaunchKernelGGL(k_iota, dim3(std::min<uint32_t>((bound + 1023u) / 1024u, 4096u)), dim3(1024), 0, st, c->d_gv[0].p, bound);
             const int rc = rs_sort_pairs(c, q_shade, c->d_gk[1].p, c->d_gv[0].p, c->d_gv[1].p, tk, tk + bound, bound, reinterpret_cast<const uint32_t*>(&ctl->n_shade), std::min(c->sort_shade_lo, sbits - 1), sbits, c->d_rs_hist.p);
@@ -2365,8 +2421,8 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t held = c->d_pool.n * sizeof(PathRec) + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7 + c->d_shq.n * sizeof(ShadowQ);   // ours, re-usable
-            const size_t per_slot = sizeof(PathRec) + 8 + 13 * 4 + 24 + 40 + (defers_shadows(c) ? sizeof(ShadowQ) * (size_t)c->S.n_light : 0);   // record, sample id, 13 queue / key words, sort scratch, staging queues, shadow queries
+            const size_t held = c->d_spool.n + c->d_lbuf.n * 8 + (c->d_qs[0].n + c->d_q[0].n) * 4 * 7 + c->d_shq.n * sizeof(ShadowQ);   // ours, re-usable
+            const size_t per_slot = GI_POOL_BYTES_PER_SLOT + 8 + 13 * 4 + 24 + 40 + (defers_shadows(c) ? sizeof(ShadowQ) * (size_t)c->S.n_light : 0);   // record, sample id, 13 queue / key words, sort scratch, staging queues, shadow queries
             const size_t lbuf = (size_t)n_pix * (size_t)std::min<size_t>((size_t)spp, c->lbuf_bytes_max / ((size_t)n_pix * 24)) * 24;
             const size_t avail = (size_t)((double)(free_b + held) * 0.90);
             if (avail > lbuf) slots_budget = std::min(slots_budget, (avail - lbuf) / per_slot);
@@ -2449,7 +2505,7 @@ static int render_adaptive(gi_ctx* c, const Frame& F, void* d_out, int out_is_f6
         if (cancel && *cancel) { c->last_launches = launches; return fail(c, GI_E_CANCELLED, "render: cancelled"); }
         HIP_TRY(c, hipMemsetAsync(cnt, 0, 4 * sizeof(unsigned int), st));
         stage_begin(c, STG_REGEN);
-        hipLaunchKernelGGL(k_ad_gen, dim3(G.ad_gen), dim3(GI_BLOCK), 0, st, c->S, F, c->d_pix.p, c->d_pool.p, c->d_slot_sample.p, n_pix, B, c->d_qs[0].p, cnt + 0);
+        hipLaunchKernelGGL(k_ad_gen, dim3(G.ad_gen), dim3(GI_BLOCK), 0, st, c->S, F, c->d_pix.p, make_path_pool(c->d_spool.p, c->spool_slots), c->d_slot_sample.p, n_pix, B, c->d_qs[0].p, cnt + 0);
         stage_end(c);
         launches++;
         HIP_TRY(c, hipMemcpyAsync(c->h_wfcnt, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
