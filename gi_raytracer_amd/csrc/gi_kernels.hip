@@ -1478,7 +1478,8 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
                 if (fl & ST_GATHER) {
                     if (MODE == 1 && S.pcand) {   // the wave carries ONE path: its lanes take a candidate each (gather_wave: the sums of gather_in_leaf to the last bit)
                         const V3 gp = ld3(p.hpos);
-                        const int32_t leaf = gather_find_leaf(S, gp);
+                        int32_t leaf = S.pdescent ? gather_find_leaf_fast(S, gp) : -2;      // the descent k_st_compact keys the queries of a pass with
+                        if (leaf == -2) leaf = gather_find_leaf(S, gp);
                         V3 caustic = v3(0, 0, 0);
                         if (leaf >= 0) {
                             const int32_t rank = S.pleaf_rank[leaf];

@@ -143,8 +143,8 @@ int gi_set_content_culling(gi_ctx*, int enable);
  * opaque entity inside its leaf, content boxes made of those, no look behind the best hit -- and with them the re-walk of a ray that met two
  * entities at exactly the same distance, and the plain walk of rays along an axis plane (gi_device.h: trace_wide_step).       */
 int gi_set_entity_boxes(gi_ctx*, int enable);
-/* Upper bound on paths in flight in the wavefront pipeline (224 B each).  Default: as many as 80 % of the free HBM holds,
- * up to the whole frame (1080p x 256 spp = 531 M paths = 119 GB).                                                           */
+/* Upper bound on paths in flight in the wavefront pipeline (232 B each, as field arrays).  Default: as many as 90 % of the free HBM holds
+ * next to their queues, up to the whole frame (1080p x 256 spp = 531 M paths = 123 GB).                                                           */
 int gi_set_pool_slots(gi_ctx*, int64_t slots);
 /* Device time in ms of the render kernel(s) of the last gi_render_* call, measured with hipEvents on the launch stream. */
 int gi_last_render_ms(gi_ctx*, float* ms, int32_t* n_launches);
