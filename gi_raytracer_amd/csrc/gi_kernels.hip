@@ -770,8 +770,9 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
 
 __global__ void k_iota(uint32_t* v, uint32_t n) { for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i; }
 
-// the walk-free instance fits its registers at 2 waves per SIMD without a spill and runs faster that way (128.. VGPRs, 4 waves: 260 B of
-// scratch per lane, 144 ms on the benchmark; 3 waves 128 ms; 2 waves 128 ms) -- with no walk in it there is little latency left to hide
+// the walk-free instance fits its registers at 2 waves per SIMD without a spill and runs fastest that way (round 2, records: 4 waves 260 B of scratch per
+// lane, 144 ms on the benchmark; 3 waves 128 ms; 2 waves 128 ms.  Round 3, field arrays, the path held in registers: 229 VGPRs, 58 ms at 2 waves; 3 waves
+// spill 212 B: 65 ms)
 #ifndef GI_DEFER_WAVES
 #define GI_DEFER_WAVES 2
 #endif
@@ -815,14 +816,47 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
         so.key = 0; so.gpos = v3(0, 0, 0);
         if (valid) {
             slot = q_shade[i];
-            PathRef pr = pool[slot];
             if constexpr (DEFER != 0) {
                 const int nl = DEFER == 2 ? S.n_light : 1;          // one query per light, the queries of item i side by side
                 ShadowQ* const e = shq + (size_t)(q_orig ? q_orig[i] : i) * (size_t)nl;   // q_orig: the item's place in the queue the shadow kernel follows (the trace stage's order)
-                fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, pr, seed, nullptr, &so, nullptr, e);
+                // the path in registers: its arrays are read up front, whole records at a time (the loads of one vertex in flight together), and
+                // written back as whole records -- only those the vertex changed, and nothing at all for a path that ends here
+                PathRec p;
+                {
+                    const PoolRay r = pool.ray[slot];
+                    const PoolHit h = pool.hit[slot];
+                    for (int k = 0; k < 3; k++) { p.o[k] = r.o[k]; p.d[k] = r.d[k]; p.hpos[k] = h.hpos[k]; }
+                    p.stream = r.stream; p.depth = r.depth; p.htri = h.htri; p.pad = h.mf; p.hu = h.hu; p.hv = h.hv;
+                    if (r.depth != 0) { const PoolThru t = pool.thru[slot]; for (int k = 0; k < 3; k++) { p.T[k] = t.T[k]; p.contrib[k] = t.contrib[k]; } }
+                    if (FEAT & GI_FEAT_TEX) { p.gdir[0] = pool.gath[slot].gdir[0]; p.gdir[1] = pool.gath[slot].gdir[1]; }
+                }
+                const V3 hp0 = ld3(p.hpos);
+                p.L[0] = NAN;                                       // (written only for an emitting surface: its A0, a finite number)
+                fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, p, seed, nullptr, &so, nullptr, e);
+                if (fl != 0) {
+                    PoolRay r;
+                    for (int k = 0; k < 3; k++) { r.o[k] = p.o[k]; r.d[k] = p.d[k]; }
+                    r.stream = p.stream; r.depth = p.depth; r.pad_[0] = 0u; r.pad_[1] = 0u;
+                    pool.ray[slot] = r;
+                    PoolThru t;
+                    for (int k = 0; k < 3; k++) { t.T[k] = p.T[k]; t.contrib[k] = p.contrib[k]; }
+                    pool.thru[slot] = t;
+                    if (fl & ST_GATHER) {
+                        PoolGath gq;
+                        for (int k = 0; k < 3; k++) { gq.gdir[k] = p.gdir[k]; gq.gcoef[k] = p.gcoef[k]; }
+                        pool.gath[slot] = gq;
+                    }
+                    if (p.L[0] == p.L[0]) { double* Lp = pool.L + (size_t)slot * 3; Lp[0] = p.L[0]; Lp[1] = p.L[1]; Lp[2] = p.L[2]; }   // A0 of an emitting surface waits there for k_st_shadow
+                }
+                if ((FEAT & GI_FEAT_FOG) && (p.hpos[0] != hp0.x || p.hpos[1] != hp0.y || p.hpos[2] != hp0.z)) {   // the segment ended in the medium: the gather of this vertex uses the scatter point
+                    PoolHit& h = pool.hit[slot];
+                    h.hpos[0] = p.hpos[0]; h.hpos[1] = p.hpos[1]; h.hpos[2] = p.hpos[2];
+                }
                 for (int li = 0; li < nl; li++) { e[li].idx = (uint32_t)(slot_sample[slot] - sample0); e[li].slot = slot; }
-            } else
+            } else {
+                PathRef pr = pool[slot];
                 fl = stage_shade_nodes<FEAT>(S, N, pr, seed, nullptr, &so, lbuf + (slot_sample[slot] - sample0) * 3);
+            }
         }
         // a path with a pending gather stays alive one more pass even when it may not continue: the trace stage retires it
         const bool cont = valid && (fl & (ST_CONTINUE | ST_GATHER)) != 0;
