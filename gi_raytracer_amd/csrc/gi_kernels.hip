@@ -282,10 +282,11 @@ struct PathPool {
 };
 __device__ __forceinline__ void pool_begin(const PathPool& pool, size_t slot, const Ray& ray, uint32_t sample)   // a new path: one 64-byte store (path_begin_lean)
 {
-    PoolRay& r = pool.ray[slot];
+    PoolRay r;
     r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z;
     r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z;
     r.stream = sample; r.depth = 0; r.pad_[0] = 0u; r.pad_[1] = 0u;
+    pool.ray[slot] = r;
 }
 static PathPool make_path_pool(void* base, size_t n)
 {
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
     auto retire = [&](uint32_t i, uint32_t slot, const Ray& ray, uint32_t stream, int32_t depth, bool hit, const HitRec& h) {
         const bool gen = i < g.n_gen;
         if (hit) {
-            PoolHit& p = pool.hit[slot];
+            PoolHit p;                                    // put together in registers, stored whole
             if (gen) { pool_begin(pool, slot, ray, stream); slot_sample[slot] = g.id_base + i; }
             if constexpr (WIDE != 0) {
                 // the walk carries only WHICH entity it hit: hit point and barycentrics are computed again here, by the same test with the same
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
             p.hpos[0] = h.pos.x; p.hpos[1] = h.pos.y; p.hpos[2] = h.pos.z;
             p.hu = h.u; p.hv = h.v; p.htri = h.tri; p.mf = h.mf;
             }
+            pool.hit[slot] = p;
             if (FEAT & GI_FEAT_TEX) { pool.gath[slot].gdir[0] = h.tu; pool.gath[slot].gdir[1] = h.tv; }   // minUV rides in the (idle between gather and shade) gather fields
         } else if (depth <= GI_MAX_DEPTH) {
             // the path ends here with a miss: L += T * ambient (stage_trace_nodes), on the per-sample radiance buffer where the path's L lives.
@@ -832,6 +834,10 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
                 }
                 const V3 hp0 = ld3(p.hpos);
                 p.L[0] = NAN;                                       // (written only for an emitting surface: its A0, a finite number)
+                ShadowQ ql;                                         // one light: the query is put together in registers too and stored whole
+                ql.pad = 0u;
+                if constexpr (DEFER == 1) fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, p, seed, nullptr, &so, nullptr, &ql);
+                else
                 fl = stage_shade_nodes<FEAT, typename LdsSrc<WIDE>::type, DEFER>(S, N, p, seed, nullptr, &so, nullptr, e);
                 if (fl != 0) {
                     PoolRay r;
@@ -852,6 +858,8 @@ __global__ __launch_bounds__(GI_SHADE_BLOCK, DEFER ? GI_DEFER_WAVES : 4) void k_
                     PoolHit& h = pool.hit[slot];
                     h.hpos[0] = p.hpos[0]; h.hpos[1] = p.hpos[1]; h.hpos[2] = p.hpos[2];
                 }
+                if constexpr (DEFER == 1) { ql.idx = (uint32_t)(slot_sample[slot] - sample0); ql.slot = slot; *e = ql; }
+                else
                 for (int li = 0; li < nl; li++) { e[li].idx = (uint32_t)(slot_sample[slot] - sample0); e[li].slot = slot; }
             } else {
                 PathRef pr = pool[slot];
