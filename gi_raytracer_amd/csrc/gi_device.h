@@ -1813,7 +1813,7 @@ struct ShadeOut { uint32_t key; V3 gpos; };   // by-products of the shade stage 
 // emissive) to the path's radiance, so the shade stage can leave the walk to a kernel of its own (k_st_shadow: lanes take a new query as
 // soon as theirs is answered) that adds the one or the other to the per-sample buffer.  A0 is zero unless the surface emits; then it waits
 // in the record's (otherwise idle) L field.  Same bits as the inline form.
-struct ShadowQ { double o[3], dir[3], A[3]; uint32_t idx, stream; int32_t depth; uint32_t live, slot, pad; };   // 96 B; idx = the sample's place in the radiance buffer; live: 0 no query, 1 query, 2 query + A0
+struct alignas(16) ShadowQ { double o[3], dir[3], A[3]; uint32_t idx, stream; int32_t depth; uint32_t live, slot, pad; };   // 96 B; idx = the sample's place in the radiance buffer; live: 0 no query, 1 query, 2 query + A0
 // stage 2: shading of the hit: secondaryRay, direct light with shadow rays, Russian roulette, next ray.
 // Lext: where the path's radiance accumulates when it does not live in the record (streaming pipeline: the per-sample radiance buffer,
 // so that a path that ends -- 96 % of the benchmark's reflected rays leave the scene -- has nothing left to read or write); else p.L.

@@ -249,10 +249,10 @@ __device__ __forceinline__ void flush_walk_cnt(unsigned long long* dst6, const W
 // path.  A stage wants 40 - 160 bytes of a path; out of records it moved whole DRAM pages for them (exp/aos_bench.hip: the shade stage's
 // read-104-write-172 pattern costs 48 ms per 477 M records as 224-byte structures, 24 ms as field arrays).  pool[slot] gives a PathRef -- the field
 // names of PathRec as references -- so the stage functions (templates on the path type) read and write exactly the fields they did.
-struct PoolRay  { double o[3], d[3]; uint32_t stream; int32_t depth; uint32_t pad_[2]; };   // 64 B: all a new path consists of, all the trace stage reads
-struct PoolHit  { double hpos[3], hu, hv; int32_t htri; uint32_t mf; };                     // 48 B: what the trace stage leaves for the shade stage
-struct PoolThru { double T[3], contrib[3]; };                                               // 48 B
-struct PoolGath { double gdir[3], gcoef[3]; };                                              // 48 B: the pending photon gather (and minUV between trace and shade)
+struct alignas(16) PoolRay  { double o[3], d[3]; uint32_t stream; int32_t depth; uint32_t pad_[2]; };   // 64 B: all a new path consists of, all the trace stage reads
+struct alignas(16) PoolHit  { double hpos[3], hu, hv; int32_t htri; uint32_t mf; };                     // 48 B: what the trace stage leaves for the shade stage
+struct alignas(16) PoolThru { double T[3], contrib[3]; };                                               // 48 B
+struct alignas(16) PoolGath { double gdir[3], gcoef[3]; };                                              // 48 B: the pending photon gather (and minUV between trace and shade)
 struct PathRef {
     double (&o)[3]; double (&d)[3]; uint32_t& stream; int32_t& depth; int32_t& htri; uint32_t& pad;
     double (&T)[3]; double (&contrib)[3]; double (&gdir)[3]; double (&gcoef)[3]; double (&hpos)[3]; double& hu; double& hv; double (&L)[3];
