@@ -164,11 +164,15 @@ struct Scene {
     double ambient[3];
     double root_bmin[3], root_bmax[3];   // box of octree node 0 (kernel argument: no memory round trip before a walk starts)
     double pmap_bmin[3], pmap_bmax[3];   // box of the photon map's root (gather_find_leaf_fast)
-    const int32_t* pjump;     // [32][32][32] (y, z, x) the node the descent of a position in that cell of the map's box has reached after five levels (or its leaf); null = not used
+    const int32_t* pjump;     // [N][N][N] (y, z, x; N = GI_PJUMP_N) the node the descent of a position in that cell of the map's box has reached after GI_PJUMP_BITS levels (or its leaf); null = not used
     double pjump_cell[3], pjump_inv[3];   // a cell's size per axis and its inverse
     double cut_margin;        // >= 0: a closest-hit walk looks no further than its best hit plus this (trace_wide_step); < 0: it walks on as the reference does
 };
 
+#ifndef GI_PJUMP_BITS
+#define GI_PJUMP_BITS 7          // levels of the photon octree the jump table of gather_find_leaf_fast covers: a grid of 128^3 cells, 8 MB (5: 22.3 ms of queue compaction + gather keys on the benchmark, 6: 21.1, 7: 19.9)
+#endif
+#define GI_PJUMP_N (1 << GI_PJUMP_BITS)
 struct Counters { unsigned long long v_trace, v_shadow, tri, shaded, pcand, traces, shadows, gathers; };
 
 // ------------------------------------------------------------------------------------------------ vec3 in glm operand order
@@ -1523,7 +1527,7 @@ GI_HD int32_t gather_find_leaf_fast(const Scene& S, V3 pos)
     for (int ax = 0; ax < 3; ax++) if (!(p[ax] > S.pmap_bmin[ax] + eps && p[ax] < S.pmap_bmax[ax] - eps)) return -2;
     int32_t node = 0;
     if (S.pjump) {
-        // the first five levels at once: the cell of a 32^3 grid over the map's box the position lies in names the node its descent reaches (the split
+        // the first GI_PJUMP_BITS levels at once: the cell of a grid over the map's box the position lies in names the node its descent reaches (the split
         // planes of those levels were checked against the grid's when the table was made: within 1e-12 of the extent); a position within 4 eps of a cell's
         // face starts at the root instead
         int cell[3];
@@ -1531,12 +1535,12 @@ GI_HD int32_t gather_find_leaf_fast(const Scene& S, V3 pos)
         for (int ax = 0; ax < 3; ax++) {
             const double f = (p[ax] - S.pmap_bmin[ax]) * S.pjump_inv[ax];
             int i = (int)f;
-            i = i < 0 ? 0 : (i > 31 ? 31 : i);
+            i = i < 0 ? 0 : (i > GI_PJUMP_N - 1 ? GI_PJUMP_N - 1 : i);
             const double lo = S.pmap_bmin[ax] + (double)i * S.pjump_cell[ax];
             if (!(p[ax] - lo > 4.0 * eps && lo + S.pjump_cell[ax] - p[ax] > 4.0 * eps)) clear = false;
             cell[ax] = i;
         }
-        if (clear) node = S.pjump[(cell[1] * 32 + cell[2]) * 32 + cell[0]];
+        if (clear) node = S.pjump[(cell[1] * GI_PJUMP_N + cell[2]) * GI_PJUMP_N + cell[0]];
     }
     for (;;) {
         const PDescent nd = S.pdescent[node];

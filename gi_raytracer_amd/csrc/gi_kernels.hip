@@ -1066,22 +1066,22 @@ __global__ __launch_bounds__(256) void k_pdescent(const PNode* nodes, int32_t n,
     d.first_child = nodes[i].first_child; d.pad = 0;
     out[i] = d;
 }
-// The jump table of gather_find_leaf_fast: for every cell of a 32^3 grid over the map's box the node five levels down (or the leaf above that) on the way of
+// The jump table of gather_find_leaf_fast: for every cell of a grid of GI_PJUMP_N^3 cells over the map's box the node GI_PJUMP_BITS levels down (or the leaf above that) on the way of
 // the cell's centre.  *bad is raised when a split plane met on the way is not the grid's plane of that level to within 1e-12 of the extent (the reference
 // computes "the middle" in three ways that differ in the last bit, no more): the table is then not used.
 __global__ __launch_bounds__(256) void k_pjump(const PDescent* pd, const double* bmin3, const double* cell3, double eps, int32_t* out, int* bad)
 {
     const int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= 32 * 32 * 32) return;
-    const int cell[3] = {i & 31, i >> 10, (i >> 5) & 31};       // x fastest, then z, then y
+    if (i >= GI_PJUMP_N * GI_PJUMP_N * GI_PJUMP_N) return;
+    const int cell[3] = {i & (GI_PJUMP_N - 1), i >> (2 * GI_PJUMP_BITS), (i >> GI_PJUMP_BITS) & (GI_PJUMP_N - 1)};       // x fastest, then z, then y
     int32_t node = 0;
-    for (int level = 0; level < 5; level++) {
+    for (int level = 0; level < GI_PJUMP_BITS; level++) {
         const PDescent nd = pd[node];
         if (nd.first_child < 0) break;
         int k = 0;
         for (int ax = 0; ax < 3; ax++) {
-            const int top = cell[ax] >> (4 - level);                                        // the cell's index among this level's 2^(level+1) halves
-            const double plane = bmin3[ax] + (double)(((top >> 1) * 2 + 1) << (4 - level)) * cell3[ax];   // the grid's middle of the node's interval
+            const int top = cell[ax] >> (GI_PJUMP_BITS - 1 - level);                                        // the cell's index among this level's 2^(level+1) halves
+            const double plane = bmin3[ax] + (double)(((top >> 1) * 2 + 1) << (GI_PJUMP_BITS - 1 - level)) * cell3[ax];   // the grid's middle of the node's interval
             if (!(fabs(nd.mid[ax] - plane) <= eps)) *bad = 1;
             if (top & 1) k |= ax == 0 ? 1 : (ax == 2 ? 2 : 4);
         }
@@ -1909,15 +1909,15 @@ static int install_pleaf_rank(gi_ctx* c)
         S.pjump = nullptr;
         if (c->descent_jump) {
             double ext = 0.0, host[7];
-            for (int k = 0; k < 3; k++) { ext = std::max(ext, root.bmax[k] - root.bmin[k]); S.pjump_cell[k] = (root.bmax[k] - root.bmin[k]) / 32.0; S.pjump_inv[k] = 32.0 / (root.bmax[k] - root.bmin[k]); }
+            for (int k = 0; k < 3; k++) { ext = std::max(ext, root.bmax[k] - root.bmin[k]); S.pjump_cell[k] = (root.bmax[k] - root.bmin[k]) / (double)GI_PJUMP_N; S.pjump_inv[k] = (double)GI_PJUMP_N / (root.bmax[k] - root.bmin[k]); }
             bool ok = ext > 0.0;
             for (int k = 0; k < 3; k++) { host[k] = root.bmin[k]; host[3 + k] = S.pjump_cell[k]; if (!(S.pjump_cell[k] > 0.0) || !std::isfinite(S.pjump_inv[k])) ok = false; }
             if (ok) {
-                if (c->d_pjump.n < 32768) HIP_TRY(c, c->d_pjump.alloc(32768));
+                if (c->d_pjump.n < (size_t)GI_PJUMP_N * GI_PJUMP_N * GI_PJUMP_N) HIP_TRY(c, c->d_pjump.alloc((size_t)GI_PJUMP_N * GI_PJUMP_N * GI_PJUMP_N));
                 if (c->d_pjump_aux.n < 8) HIP_TRY(c, c->d_pjump_aux.alloc(8));
                 host[6] = 0.0;                                                    // (as an int: the "bad" flag)
                 HIP_TRY(c, hipMemcpyAsync(c->d_pjump_aux.p, host, sizeof host, hipMemcpyHostToDevice, c->stream));
-                hipLaunchKernelGGL(k_pjump, dim3(128), dim3(256), 0, c->stream, c->d_pdescent.p, c->d_pjump_aux.p, c->d_pjump_aux.p + 3, 1e-12 * ext, c->d_pjump.p, reinterpret_cast<int*>(c->d_pjump_aux.p + 6));
+                hipLaunchKernelGGL(k_pjump, dim3((unsigned)((GI_PJUMP_N * GI_PJUMP_N * GI_PJUMP_N + 255) / 256)), dim3(256), 0, c->stream, c->d_pdescent.p, c->d_pjump_aux.p, c->d_pjump_aux.p + 3, 1e-12 * ext, c->d_pjump.p, reinterpret_cast<int*>(c->d_pjump_aux.p + 6));
                 HIP_TRY(c, hipGetLastError());
                 int bad = 1;
                 HIP_TRY(c, hipMemcpyAsync(&bad, c->d_pjump_aux.p + 6, sizeof bad, hipMemcpyDeviceToHost, c->stream));

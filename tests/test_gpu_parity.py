@@ -219,7 +219,7 @@ def test_quick_descent_of_the_gather_keys_finds_the_same_leaf(jump, monkeypatch)
     plane = boxes[np.arange(k), ax + 3 * rs.randint(2, size=k)]
     off = np.where(rs.rand(k) < 0.3, 0.0, ext * 10.0 ** rs.uniform(-15, -9, k) * rs.choice([-1, 1], k))
     pos[np.arange(k), ax] = plane + off
-    grid = root[:3] + (root[3:] - root[:3]) * rs.randint(0, 33, size=(k, 3)) / 32.0      # the jump table's own cell faces
+    grid = root[:3] + (root[3:] - root[:3]) * rs.randint(0, 129, size=(k, 3)) / 128.0      # cell faces of the jump table (32, 64 or 128 cells per axis)
     pos[k:2 * k][np.arange(k), ax] = grid[np.arange(k), ax] + off
     fast, full = rt.find_leaves(pos)
     took = fast != -2
