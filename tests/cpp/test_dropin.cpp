@@ -23,6 +23,12 @@ int main(int argc, char** argv)
     printf("lights %zu photons %d samples %d..%d up %.6f %.6f %.6f\n", scene->lights.size(), copy.photons, copy.min_samples, copy.max_samples,
            copy._camera.up.x, copy._camera.up.y, copy._camera.up.z);
     if (scene->lights.size()) printf("light0 angle %.12f\n", scene->lights[0]->angle);
+    if (scene->lights.size()) {   // Light::getPoint() / getPoint(i): the table of 250 directions (include/light.h:17-40)
+        Light& l = *scene->lights[0];
+        const gi::dvec3 a = l.points[125], g0 = l.getPoint() - l.pos, g1 = l.getPoint(7) - l.pos;
+        printf("light0 points %zu p125 %.17g %.17g %.17g getPoint %.12f %.12f rad %.12f\n", l.points.size(), a.x, a.y, a.z,
+               std::sqrt(g0.x * g0.x + g0.y * g0.y + g0.z * g0.z), std::sqrt(g1.x * g1.x + g1.y * g1.y + g1.z * g1.z), l.rad);
+    }
     // programmatic scene as the mesh generators build it (entities.h:721-738): two triangles and a light
     Octree* quad = new Octree();
     texture white(gi::dvec3(1, 1, 1)), black(gi::dvec3(0, 0, 0));

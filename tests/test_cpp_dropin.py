@@ -22,6 +22,15 @@ def test_host_side_of_the_dropin_api():
     assert "lights 1 photons 750000 samples 8..32" in out           # what scenes/caustics/caustics.scn sets
     assert "light0 angle 0.079562916434" in out                     # Octree::rebuild's light cone, as the reference dump has it
     assert "quad valid 1" in out
+    # Light's table of 250 directions (include/light.h:17-40, include/util.cpp:129-155: Hammersley point -> direction) and the points picked from it
+    m = re.search(r"light0 points 250 p125 (\S+) (\S+) (\S+) getPoint (\S+) (\S+) rad (\S+)", out)
+    assert m, out
+    x = float(np.float32(125) / np.float32(250))
+    y = float(np.float32(float(np.float32(int(format(125, "032b")[::-1], 2))) * 2.3283064365386963e-10))
+    th = np.arccos(2 * y - 1)
+    want = np.array([np.sin(th) * np.cos(2 * x * np.pi), np.sin(th) * np.sin(2 * x * np.pi), np.cos(th)])
+    assert np.allclose([float(m.group(k)) for k in (1, 2, 3)], want, rtol=0, atol=1e-15)
+    assert abs(float(m.group(4)) - float(m.group(6))) < 1e-11 and abs(float(m.group(5)) - float(m.group(6))) < 1e-11   # on the light's sphere
 
 
 def test_dropin_texture_classes_match_the_reference(golden):
