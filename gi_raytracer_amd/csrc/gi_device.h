@@ -144,7 +144,8 @@ struct Scene {
     const int32_t* prank_leaf;   // [n_pleaf] its inverse
     int32_t n_pleaf;             // leaves with candidates
     const uint32_t* pcand_off;   // [n_pleaf + 1] where the candidate list of the leaf of that rank begins in pcand; null = not used
-    const int32_t* pcand;        // photon indices: the ranges of every such leaf written out back to back, in the order gather_in_leaf visits them (k_st_gather)
+    const double* pcand;         // [total][3] the candidates' POSITIONS: the ranges of every such leaf written out back to back, in the order gather_in_leaf visits them (k_st_gather)
+    const double* pcand_dc;      // [total][6] and their direction and colour (read by the second pass)
     const PRange* pranges;
     const double* ph_pos;     // [n_photon][3] leaf order
     const double* ph_dircol;  // [n_photon][6] leaf order

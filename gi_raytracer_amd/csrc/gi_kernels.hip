@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__(256) void k_pcand_count(const PNode* nodes, const i
     const int32_t r = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
     if (r <= n_pleaf) cnt[r] = r < n_pleaf ? (uint32_t)nodes[inv[r]].u.lf.nb_photons : 0u;
 }
-__global__ __launch_bounds__(256) void k_pcand_fill(const PNode* nodes, const PRange* pranges, const int32_t* inv, int32_t n_pleaf, const uint32_t* off, int32_t* out)
+__global__ __launch_bounds__(256) void k_pcand_fill(const PNode* nodes, const PRange* pranges, const double* ph_pos, const double* ph_dircol, const int32_t* inv, int32_t n_pleaf, const uint32_t* off,
+                                                   double* out_pos, double* out_dc)
 {
     // a wave per leaf: its ranges one after the other, a range's photons across the lanes
     const int32_t wave = (int32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int32_t)(threadIdx.x & 63u), n_waves = (int32_t)((gridDim.x * blockDim.x) >> 6);
@@ -1052,7 +1053,11 @@ __global__ __launch_bounds__(256) void k_pcand_fill(const PNode* nodes, const PR
         uint32_t at = off[r];
         for (int32_t k = 0; k < lf.u.lf.nb_cnt; k++) {
             const PRange rg = ranges[k];
-            for (int32_t j = lane; j < rg.count; j += 64) out[at + (uint32_t)j] = rg.first + j;
+            for (int32_t j = lane; j < rg.count; j += 64) {          // the photon itself, not its index: one read less between a leaf and its candidates
+                const size_t src = (size_t)(rg.first + j), dst = (size_t)at + (size_t)j;
+                for (int k = 0; k < 3; k++) out_pos[dst * 3 + k] = ph_pos[src * 3 + k];
+                for (int k = 0; k < 6; k++) out_dc[dst * 6 + k] = ph_dircol[src * 6 + k];
+            }
             at += (uint32_t)rg.count;
         }
     }
@@ -1257,19 +1262,20 @@ __global__ __launch_bounds__(GI_BLOCK, GI_GATHER_WAVES) void k_st_gather(Scene S
                 const int32_t m = min((int32_t)GI_GCHUNK, ncand - c0);
                 __builtin_amdgcn_wave_barrier();
                 if ((int32_t)lane < m) {
-                    size_t ph;
-                    if (S.pcand) ph = (size_t)S.pcand[S.pcand_off[rank0] + (uint32_t)(c0 + (int32_t)lane)];
-                    else {
+                    const double* pp;
+                    const double* dc;
+                    if (S.pcand) {
+                        const size_t at = (size_t)S.pcand_off[rank0] + (size_t)(c0 + (int32_t)lane);
+                        pp = S.pcand + at * 3; dc = S.pcand_dc + at * 6;
+                    } else {
                         int32_t off = c0 + (int32_t)lane, r = 0;
                         while (off >= ranges[r].count) { off -= ranges[r].count; r++; }   // r < n_ranges: off < ncand = sum of the counts
-                        ph = (size_t)(ranges[r].first + off);
+                        const size_t ph = (size_t)(ranges[r].first + off);
+                        pp = S.ph_pos + ph * 3; dc = S.ph_dircol + ph * 6;
                     }
-                    const double* pp = S.ph_pos + ph * 3;
                     cand[lane][0] = pp[0]; cand[lane][1] = pp[1]; cand[lane][2] = pp[2];
-                    if (pass == 1) {
-                        const double* dc = S.ph_dircol + ph * 6;
+                    if (pass == 1)
                         for (int k = 0; k < 6; k++) cand[lane][3 + k] = dc[k];
-                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1370,7 +1376,7 @@ __device__ __forceinline__ V3 gather_wave(const Scene& S, int32_t leaf, uint32_t
     if (n_cand_out) *n_cand_out = ncand;
     V3 res = v3(0, 0, 0);
     if (ncand == 0) return res;
-    const int32_t* cand = S.pcand + S.pcand_off[rank];
+    const size_t cbase = (size_t)S.pcand_off[rank];
     const int K = ncand < GI_GATHER_K ? ncand : GI_GATHER_K;
     // pass 1: the K-th smallest float key.  lane j < 32 holds the j-th smallest so far
     float best = INFINITY;
@@ -1378,7 +1384,7 @@ __device__ __forceinline__ V3 gather_wave(const Scene& S, int32_t leaf, uint32_t
         const int32_t c = c0 + (int32_t)lane;
         float key = INFINITY;
         if (c < ncand) {
-            const double* pp = S.ph_pos + (size_t)cand[c] * 3;
+            const double* pp = S.pcand + (cbase + (size_t)c) * 3;
             key = (float)len2(v3(pp[0], pp[1], pp[2]) - pos);            // the expression of g_key
         }
 #pragma unroll
@@ -1409,13 +1415,12 @@ __device__ __forceinline__ V3 gather_wave(const Scene& S, int32_t leaf, uint32_t
         double d2 = 0;
         V3 contrib = v3(0, 0, 0);
         if (c < ncand) {
-            const int32_t idx = cand[c];
-            const double* pp = S.ph_pos + (size_t)idx * 3;
+            const double* pp = S.pcand + (cbase + (size_t)c) * 3;
             d2 = len2(v3(pp[0], pp[1], pp[2]) - pos);
             const float key = (float)d2;
             lt = key < tau; eq = key == tau;
             if (lt || eq) {
-                const double* dc = S.ph_dircol + (size_t)idx * 6;
+                const double* dc = S.pcand_dc + (cbase + (size_t)c) * 6;
                 contrib = v3(dc[3], dc[4], dc[5]) * dot(v3(dc[0], dc[1], dc[2]), dir);
             }
         }
@@ -1759,7 +1764,7 @@ struct gi_ctx {
     bool cull_enabled = true;         // gi_set_content_culling
     bool flat_candidates = true;      // GI_FLAT_CANDIDATES=0: k_st_gather finds a leaf's k-th candidate through its range list, no k_st_gather_wave
     DevBuf<uint32_t> d_pcand_off;
-    DevBuf<int32_t> d_pcand;
+    DevBuf<double> d_pcand, d_pcand_dc;
     uint32_t gather_wave_below = 200000u;    // GI_GATHER_WAVE_BELOW: gather passes with fewer queries give every query a wave (k_st_gather_wave)
     bool descent_jump = true;         // GI_DESCENT_JUMP=0: the fast descent of the gather keys starts at the root
     DevBuf<int32_t> d_pjump;          // its jump table (gi_device.h: gather_find_leaf_fast)
@@ -1870,7 +1875,7 @@ __global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* ghist, uint32_t tota
 static int install_pleaf_rank(gi_ctx* c)
 {
     Scene& S = c->S;
-    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0; S.pdescent = nullptr; S.pjump = nullptr; S.pcand_off = nullptr; S.pcand = nullptr;
+    S.pleaf_rank = nullptr; S.prank_leaf = nullptr; S.n_pleaf = 0; S.pdescent = nullptr; S.pjump = nullptr; S.pcand_off = nullptr; S.pcand = nullptr; S.pcand_dc = nullptr;
     if (S.n_pnode <= 0) return GI_OK;
     if (c->d_pleaf_rank.n < (size_t)S.n_pnode) { HIP_TRY(c, c->d_pleaf_rank.alloc((size_t)S.n_pnode)); HIP_TRY(c, c->d_prank_leaf.alloc((size_t)S.n_pnode)); }
     if (!c->d_n_pleaf.p) HIP_TRY(c, c->d_n_pleaf.alloc(1));
@@ -1880,7 +1885,7 @@ static int install_pleaf_rank(gi_ctx* c)
     HIP_TRY(c, hipMemcpyAsync(&n, c->d_n_pleaf.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     S.pleaf_rank = c->d_pleaf_rank.p; S.prank_leaf = c->d_prank_leaf.p; S.n_pleaf = n;
-    S.pcand_off = nullptr; S.pcand = nullptr;
+    S.pcand_off = nullptr; S.pcand = nullptr; S.pcand_dc = nullptr;
     if (c->flat_candidates && n > 0) {
         if (c->d_pcand_off.n < (size_t)n + 1) HIP_TRY(c, c->d_pcand_off.alloc((size_t)n + 1));
         hipLaunchKernelGGL(k_pcand_count, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, c->stream, S.pnodes, c->d_prank_leaf.p, n, c->d_pcand_off.p);
@@ -1890,10 +1895,10 @@ static int install_pleaf_rank(gi_ctx* c)
         HIP_TRY(c, hipMemcpyAsync(&total, c->d_pcand_off.p + n, sizeof total, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (total > 0 && total < 0x7fffffffu) {
-            if (c->d_pcand.n < (size_t)total) HIP_TRY(c, c->d_pcand.alloc((size_t)total));
-            hipLaunchKernelGGL(k_pcand_fill, dim3(1024), dim3(256), 0, c->stream, S.pnodes, S.pranges, c->d_prank_leaf.p, n, c->d_pcand_off.p, c->d_pcand.p);
+            if (c->d_pcand.n < (size_t)total * 3) { HIP_TRY(c, c->d_pcand.alloc((size_t)total * 3)); HIP_TRY(c, c->d_pcand_dc.alloc((size_t)total * 6)); }
+            hipLaunchKernelGGL(k_pcand_fill, dim3(1024), dim3(256), 0, c->stream, S.pnodes, S.pranges, S.ph_pos, S.ph_dircol, c->d_prank_leaf.p, n, c->d_pcand_off.p, c->d_pcand.p, c->d_pcand_dc.p);
             HIP_TRY(c, hipGetLastError());
-            S.pcand_off = c->d_pcand_off.p; S.pcand = c->d_pcand.p;
+            S.pcand_off = c->d_pcand_off.p; S.pcand = c->d_pcand.p; S.pcand_dc = c->d_pcand_dc.p;
         }
     }
     // the split records of the descent and the map's own box (gather_find_leaf_fast); the one-record-per-level layout only (children from the parent's planes)
