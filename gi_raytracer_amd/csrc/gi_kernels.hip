@@ -1490,9 +1490,11 @@ __global__ __launch_bounds__(GI_GW_BLOCK) void k_st_gather_wave(Scene S, PathPoo
 #define GI_FINISH_COOP_LDS_BYTES (GI_FINISH_COOP_HEAP_OFF + (GI_FINISH_BLOCK / 16) * GI_GATHER_K * 4)
 __device__ __forceinline__ int finish_mode(int wide, int lanes, uint32_t n_in, uint32_t n_waves, uint32_t coop_factor)
 {
+    // coop_factor: low half = paths per group-of-16 slot up to which a stage runs one path per group, high half = paths per resident wave up to which it
+    // runs one path per WAVE (the wave's lanes walk the nodes together, test a leaf's entities side by side and take a gather candidate each)
     if (!wide || lanes > 0) return 0;
-    if (n_in <= 2u * n_waves) return 1;                    // up to two paths per wave in a row: still faster than four side by side
-    if (n_in <= coop_factor * 4u * n_waves) return 2;
+    if (n_in <= (coop_factor >> 16) * n_waves) return 1;
+    if (n_in <= (coop_factor & 0xffffu) * 4u * n_waves) return 2;
     return 0;
 }
 template <int FEAT, int WIDE, int MODE>
@@ -1838,7 +1840,8 @@ struct gi_ctx {
     float stage_ms[STG_COUNT_MAX] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int render_mode = 0;              // 0 wavefront pipeline, 1 megakernel
     size_t pool_slots_max = (size_t)1 << 30;    // upper bound on paths in flight; the actual pool is also bounded by free HBM (render_streaming)
-    uint32_t finish_threshold = 1u << 17;
+    uint32_t finish_threshold = 1u << 17;   // GI_FINISH_THRESHOLD: paths left when the finisher takes over
+    uint32_t wave_factor = 0;         // GI_WAVE_FACTOR: finisher stages with at most this many paths per resident wave run one path per wave; 0 = by the size of the frame (stream_passes)
     uint32_t coop_factor = 4;         // finisher stages with at most 4 x coop_factor x (resident waves) paths run one path per group of 16 lanes (at most 2 x: one per wave)
     // finisher stages {paths per wave (0: spread evenly over the resident waves), max vertices}; the last stage runs to MAX_DEPTH.
     // Measured on the default frame (tools/stripe_probe.py): one full-wave stage 60 ms, this plan 51 ms; on 1/8 of the rows 40 -> 30 ms.
@@ -1963,6 +1966,7 @@ int gi_create(gi_ctx** out, int device_ordinal)
     c->S.htable = c->d_htable.p;
     if (const char* e = getenv("GI_LBUF_MAX_BYTES")) c->lbuf_bytes_max = (size_t)strtoull(e, nullptr, 0);   // per-sample radiance buffer: frames beyond it run in sample chunks
     if (const char* e = getenv("GI_COOP_FACTOR")) c->coop_factor = (uint32_t)strtoul(e, nullptr, 0);
+    if (const char* e = getenv("GI_WAVE_FACTOR")) c->wave_factor = std::min<uint32_t>((uint32_t)strtoul(e, nullptr, 0), 0xffffu);
     if (const char* e = getenv("GI_SORT_CONT")) c->sort_cont = atoi(e) != 0;
     if (const char* e = getenv("GI_DESCENT_JUMP")) c->descent_jump = atoi(e) != 0;
     if (const char* e = getenv("GI_FLAT_CANDIDATES")) c->flat_candidates = atoi(e) != 0;
@@ -2283,6 +2287,12 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
                          const std::function<uint32_t(uint32_t, const uint32_t*, GenArgs&)>& refill, const bool& exhausted,
                          volatile const int* cancel, int& launches)
 {
+    // the finisher's one-path-per-wave form: up to 2 paths per resident wave (more of them side by side are faster in groups of 16: benchmark frame's
+    // finisher 19.6 ms against 27.3 with 32 per wave; closed box 4.4 against 7.0) -- except for a small frame that gathers photons, such as a rank's share
+    // of the benchmark frame on 8 GPUs (66 M samples): its tail is a larger part of it and holds fewer paths, and a lone path's gather is the wave
+    // routine's: up to 32 (a 1/8 share 60.6 ms against 64.0; tools/fin_share.sh)
+    const bool small_frame = (unsigned long long)F.w * (unsigned long long)F.local_rows * (unsigned long long)std::max(F.max_samples, 1) < 200000000ull;
+    const uint32_t wave_factor = c->wave_factor ? c->wave_factor : ((small_frame && c->S.pcand) ? 32u : 2u);
     const StreamGrids& G = stream_grids(c);
     if (G.lds_refused) return fail(c, GI_E_HIP, "render: the device refused " + std::to_string(G.lds_refused) + " bytes of dynamic LDS per workgroup (the traversal kernels are laid out for gfx950's 160 KB per CU)");
     hipStream_t st = c->stream;
@@ -2328,7 +2338,7 @@ static int stream_passes(gi_ctx* c, const Frame& F, unsigned long long sample0, 
                     constexpr int M = decltype(mode)::value;
                     hipLaunchKernelGGL(texf ? (wide ? k_st_finish<7, 1, M> : k_st_finish<7, 0, 0>) : wide ? (fogf ? k_st_finish<3, 1, M> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 1, M> : k_st_finish<0, 1, M>)) : (fogf ? k_st_finish<3, 0, 0> : (sphf ? k_st_finish<GI_FEAT_SPHERES, 0, 0> : k_st_finish<0, 0, 0>)), dim3(G.finish), dim3(GI_FINISH_BLOCK),
                                        M == 0 ? kLdsNodes : kLdsFinishCoop, st, c->S, F.seed, pool, c->d_slot_sample.p, sample0,
-                                       fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, lbuf, c->coop_factor);
+                                       fq_in, n_in_dev, n_cont, lanes, vertices, fq_out, c->d_fin_cnt.p + k, lbuf, (wave_factor << 16) | (c->coop_factor & 0xffffu));
                 };
                 fin(std::integral_constant<int, 0>());
                 if (wide && lanes <= 0) { fin(std::integral_constant<int, 1>()); fin(std::integral_constant<int, 2>()); launches += 2; }

@@ -181,8 +181,8 @@ def test_schedule_knobs_change_nothing(name, monkeypatch):
     to the put-off segment.  GI_COOP_FACTOR moves the finisher between one path per lane, per group of 16 lanes and per wave."""
     scene = pc.two_light_scene(name.endswith("glass")) if name.startswith("two_lights") else pc.load_scene(name)   # two lights: one put-off query per light
     frames = []
-    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}, {"GI_ENTITY_BOXES": "0"}, {"GI_CLIP_BOXES": "0"}, {"GI_WALK_CUT": "0"}, {"GI_SORT_CONT": "0"}, {"GI_SORT_SHADE": "0"}, {"GI_SORT_SHADE_LO": "0"}, {"GI_FAST_DESCENT": "0"}, {"GI_DESCENT_JUMP": "0"}, {"GI_FLAT_CANDIDATES": "0"}, {"GI_GATHER_WAVE_BELOW": "0"}, {"GI_GATHER_WAVE_BELOW": "4000000000"}):
-        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR", "GI_ENTITY_BOXES", "GI_CLIP_BOXES", "GI_WALK_CUT", "GI_SORT_CONT", "GI_SORT_SHADE", "GI_SORT_SHADE_LO", "GI_FAST_DESCENT", "GI_DESCENT_JUMP", "GI_FLAT_CANDIDATES", "GI_GATHER_WAVE_BELOW"):
+    for env in ({}, {"GI_DEFER_SHADOWS": "0"}, {"GI_REFILL_MIN": "64"}, {"GI_REFILL_MIN": "5"}, {"GI_COOP_FACTOR": "0"}, {"GI_COOP_FACTOR": "64"}, {"GI_WAVE_FACTOR": "1"}, {"GI_WAVE_FACTOR": "200"}, {"GI_FINISH_THRESHOLD": "1000"}, {"GI_ENTITY_BOXES": "0"}, {"GI_CLIP_BOXES": "0"}, {"GI_WALK_CUT": "0"}, {"GI_SORT_CONT": "0"}, {"GI_SORT_SHADE": "0"}, {"GI_SORT_SHADE_LO": "0"}, {"GI_FAST_DESCENT": "0"}, {"GI_DESCENT_JUMP": "0"}, {"GI_FLAT_CANDIDATES": "0"}, {"GI_GATHER_WAVE_BELOW": "0"}, {"GI_GATHER_WAVE_BELOW": "4000000000"}):
+        for k in ("GI_DEFER_SHADOWS", "GI_REFILL_MIN", "GI_COOP_FACTOR", "GI_WAVE_FACTOR", "GI_FINISH_THRESHOLD", "GI_ENTITY_BOXES", "GI_CLIP_BOXES", "GI_WALK_CUT", "GI_SORT_CONT", "GI_SORT_SHADE", "GI_SORT_SHADE_LO", "GI_FAST_DESCENT", "GI_DESCENT_JUMP", "GI_FLAT_CANDIDATES", "GI_GATHER_WAVE_BELOW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
