@@ -1488,6 +1488,38 @@ __global__ __launch_bounds__(GI_GW_BLOCK) void k_st_gather_wave(Scene S, PathPoo
 #define GI_FINISH_COOP_RECORDS GI_LDS_WNODES
 #define GI_FINISH_COOP_HEAP_OFF ((GI_LDS_BOXES_BYTES(GI_FINISH_COOP_RECORDS) + 15) & ~15)
 #define GI_FINISH_COOP_LDS_BYTES (GI_FINISH_COOP_HEAP_OFF + (GI_FINISH_BLOCK / 16) * GI_GATHER_K * 4)
+// The photon gathers the paths of a finisher wave have pending after a vertex (`pending`: this lane's -- or, with G lanes per path, this group's --
+// path has one).  Up to GI_FIN_WAVE_GATHERS of them are served by the whole wave one after the other (gather_wave); more than that (a stage that still
+// holds a path in most lanes), or no written-out candidate lists, and every path walks its own leaf as before (stage_gather).  Called by all 64 lanes.
+#ifndef GI_FIN_WAVE_GATHERS
+#define GI_FIN_WAVE_GATHERS 24
+#endif
+__device__ __forceinline__ void finish_gathers(const Scene& S, PathRec& p, bool pending, uint32_t G, float* heap, int heap_stride, float* heap32, uint32_t lane)
+{
+    unsigned long long pend = __ballot(pending && (lane & (G - 1u)) == 0u);
+    if (pend == 0ull) return;
+    if (!S.pcand || (uint32_t)__popcll(pend) > (uint32_t)GI_FIN_WAVE_GATHERS) {
+        if (pending) stage_gather(S, p, heap, heap_stride, nullptr);
+        return;
+    }
+    while (pend != 0ull) {
+        const int src = __ffsll((long long)pend) - 1;
+        pend &= pend - 1ull;
+        const V3 gp = v3(wave_read(p.hpos[0], src), wave_read(p.hpos[1], src), wave_read(p.hpos[2], src));
+        const V3 gd = v3(wave_read(p.gdir[0], src), wave_read(p.gdir[1], src), wave_read(p.gdir[2], src));
+        int32_t leaf = S.pdescent ? gather_find_leaf_fast(S, gp) : -2;      // the descent k_st_compact keys the queries of a pass with
+        if (leaf == -2) leaf = gather_find_leaf(S, gp);
+        V3 caustic = v3(0, 0, 0);
+        if (leaf >= 0) {
+            const int32_t rank = S.pleaf_rank[leaf];
+            if (rank >= 0) caustic = gather_wave(S, leaf, (uint32_t)rank, gp, gd, heap32, lane, nullptr);
+        }
+        if (lane / G == (uint32_t)src / G) {                                  // stage_gather, on the path's own lanes
+            const V3 L = ld3(p.L) + ld3(p.gcoef) * caustic;
+            p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
+        }
+    }
+}
 __device__ __forceinline__ int finish_mode(int wide, int lanes, uint32_t n_in, uint32_t n_waves, uint32_t coop_factor)
 {
     // coop_factor: low half = paths per group-of-16 slot up to which a stage runs one path per group, high half = paths per resident wave up to which it
@@ -1515,34 +1547,30 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
         float* const heap = reinterpret_cast<float*>(gi_dyn_lds + GI_FINISH_COOP_HEAP_OFF) + threadIdx.x / G;   // one heap per group, element i at heap[i * groups]
         const int heap_stride = (int)(GI_FINISH_BLOCK / G);
         const uint32_t grp = lane / G;
-        for (uint32_t i = wave * per_wave + grp; i < n_in; i += n_waves * per_wave) {
-            const uint32_t slot = q_in[i];
-            PathRec p = pool.load(slot);
-            double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;   // the path's radiance so far; kept in registers while this stage works on it
-            p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
-            bool alive = true;
+        // every lane of the wave stays in the loops (a group without a path idles): a pending photon gather is served by the WHOLE wave, one query at a
+        // time -- its lanes take a candidate each (gather_wave: gather_in_leaf's sums to the last bit).  A group's or lane's own walk through its leaf's
+        // candidates is a chain of dependent reads that the stage's other paths all wait for (0.5 - 1 ms per vertex of a stage, whatever its size).
+        float* const heap32 = reinterpret_cast<float*>(gi_dyn_lds + GI_FINISH_COOP_HEAP_OFF) + (threadIdx.x >> 6) * GI_GATHER_K;
+        for (uint32_t i0 = wave * per_wave; i0 < n_in; i0 += n_waves * per_wave) {
+            const uint32_t i = i0 + grp;
+            const bool have = i < n_in;
+            const uint32_t slot = have ? q_in[i] : 0u;
+            PathRec p;
+            double* const Lb = lbuf + (have ? (slot_sample[slot] - sample0) * 3 : 0ull);   // the path's radiance so far; kept in registers while this stage works on it
+            if (have) { p = pool.load(slot); p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2]; }
+            bool alive = have, running = have;
             for (int b = 0;;) {
-                if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; break; }
-                const int fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
-                if (fl & ST_GATHER) {
-                    if (MODE == 1 && S.pcand) {   // the wave carries ONE path: its lanes take a candidate each (gather_wave: the sums of gather_in_leaf to the last bit)
-                        const V3 gp = ld3(p.hpos);
-                        int32_t leaf = S.pdescent ? gather_find_leaf_fast(S, gp) : -2;      // the descent k_st_compact keys the queries of a pass with
-                        if (leaf == -2) leaf = gather_find_leaf(S, gp);
-                        V3 caustic = v3(0, 0, 0);
-                        if (leaf >= 0) {
-                            const int32_t rank = S.pleaf_rank[leaf];
-                            if (rank >= 0) caustic = gather_wave(S, leaf, (uint32_t)rank, gp, ld3(p.gdir), reinterpret_cast<float*>(gi_dyn_lds + GI_FINISH_COOP_HEAP_OFF) + (threadIdx.x >> 6) * GI_GATHER_K, lane, nullptr);
-                        }
-                        const V3 L = ld3(p.L) + ld3(p.gcoef) * caustic;      // stage_gather
-                        p.L[0] = L.x; p.L[1] = L.y; p.L[2] = L.z;
-                    } else
-                        stage_gather(S, p, heap, heap_stride, nullptr);
+                int fl = 0;
+                if (running) {
+                    if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; running = false; }
+                    else fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
                 }
-                if (!(fl & ST_CONTINUE)) { alive = false; break; }
-                if (++b >= max_bounces) break;
+                finish_gathers(S, p, running && (fl & ST_GATHER) != 0, G, heap, heap_stride, heap32, lane);
+                if (running && !(fl & ST_CONTINUE)) { alive = false; running = false; }
+                if (++b >= max_bounces) running = false;
+                if (__ballot(running) == 0ull) break;
             }
-            if ((lane & (G - 1u)) == 0u) {
+            if (have && (lane & (G - 1u)) == 0u) {
                 Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
                 if (alive) {
                     pool.store(slot, p);
@@ -1554,24 +1582,31 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
         __shared__ float heap[GI_GATHER_K * GI_FINISH_BLOCK];
         const typename LdsSrc<WIDE>::type N = LdsSrc<WIDE>::stage(S);   // a lone path's bounce is a chain of dependent node reads: LDS, not L2
         if (lanes <= 0) lanes = (int)min(64u, max(1u, (n_in + n_waves - 1) / n_waves));   // spread the paths evenly over the resident waves
-        if (lane >= (uint32_t)lanes) return;
-        for (uint32_t i = wave * lanes + lane; i < n_in; i += n_waves * lanes) {
-            const uint32_t slot = q_in[i];
-            PathRec p = pool.load(slot);
-            double* const Lb = lbuf + (slot_sample[slot] - sample0) * 3;
-            p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2];
-            bool alive = true;
+        for (uint32_t i0 = wave * lanes; i0 < n_in; i0 += n_waves * lanes) {
+            const uint32_t i = i0 + lane;
+            const bool have = lane < (uint32_t)lanes && i < n_in;
+            const uint32_t slot = have ? q_in[i] : 0u;
+            PathRec p;
+            double* const Lb = lbuf + (have ? (slot_sample[slot] - sample0) * 3 : 0ull);
+            if (have) { p = pool.load(slot); p.L[0] = Lb[0]; p.L[1] = Lb[1]; p.L[2] = Lb[2]; }
+            bool alive = have, running = have;
             for (int b = 0;;) {
-                if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; break; }
-                const int fl = stage_shade_nodes<FEAT>(S, N, p, seed, nullptr);
-                if (fl & ST_GATHER) stage_gather(S, p, heap + threadIdx.x, GI_FINISH_BLOCK, nullptr);
-                if (!(fl & ST_CONTINUE)) { alive = false; break; }
-                if (++b >= max_bounces) break;
+                int fl = 0;
+                if (running) {
+                    if (!stage_trace_nodes<FEAT>(S, N, p, seed, nullptr)) { alive = false; running = false; }
+                    else fl = stage_shade_nodes<FEAT>(S, N, p, seed, nullptr);
+                }
+                finish_gathers(S, p, running && (fl & ST_GATHER) != 0, 1u, heap + threadIdx.x, GI_FINISH_BLOCK, heap + (threadIdx.x & ~63u), lane);   // (heap32: row 0 of this wave's own lanes 0 .. 31)
+                if (running && !(fl & ST_CONTINUE)) { alive = false; running = false; }
+                if (++b >= max_bounces) running = false;
+                if (__ballot(running) == 0ull) break;
             }
-            Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
-            if (alive) {
-                pool.store(slot, p);
-                q_out[atomicAdd(n_out, 1u)] = slot;
+            if (have) {
+                Lb[0] = p.L[0]; Lb[1] = p.L[1]; Lb[2] = p.L[2];
+                if (alive) {
+                    pool.store(slot, p);
+                    q_out[atomicAdd(n_out, 1u)] = slot;
+                }
             }
         }
     }
