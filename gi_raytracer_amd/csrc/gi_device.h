@@ -792,6 +792,73 @@ struct WWalk {
 };
 GI_HD void wwalk_push(WWalk& k, int32_t child) { k.hi = (k.hi << 8) | (k.lo >> 56); k.lo = (k.lo << 8) | k.m; k.node = child; }
 GI_HD void wwalk_pop(WWalk& k, int32_t parent) { k.m = (uint32_t)(k.lo & 0xffull); k.lo = (k.lo >> 8) | (k.hi << 56); k.hi >>= 8; k.node = parent; }
+// The children of a record the ray enters, in its order (wide_hits), without those whose contents it misses (content_cull).  A walk that carries ONE
+// ray on a group of lanes (WN::kCoop: the finisher's lone paths, where a bounce is a chain of dependent steps and every step's length counts)
+// tests the eight children side by side, a lane each -- the same arithmetic per child (max / min of the same numbers: their order does not matter), a
+// ballot instead of eight turns of a loop: ~30 instructions a step instead of ~150.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int G> __device__ __forceinline__ unsigned long long group_ballot(bool pred);
+template <class WN>
+__device__ __forceinline__ uint32_t walk_hits_coop(const WN& W, int32_t node, const Ray& r, const WRay& wr, double tmin0, double tmax0)
+{
+    constexpr int G = WN::kGroup;
+    const int c = (int)(threadIdx.x & 7u);                        // this lane's child slot (lanes 8 .. G-1 of a group repeat the work of 0 .. 7; their votes are not looked at)
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
+    uint32_t exists = 0;
+    const bool hit = W.with(node, [&](const WNode* w) {
+        exists = w->exists;
+        const char* b = reinterpret_cast<const char*>(w);
+        const int bit[3] = {c & 1, (c >> 2) & 1, (c >> 1) & 1};   // x = bit 0, z = bit 1, y = bit 2 of a slot
+        double t0 = tmin0, t1 = tmax0;
+        for (int ax = 0; ax < 3; ax++) {
+            const int A = ax * 48, x = back_off(inv[ax]), y = x ^ 8;
+            // child 7 has planes of its own (wide_hits: n[ax][2] from the far-side entry, f[ax][2] from the near-side one)
+            const int en = c == 7 ? A + 32 + y : A + 16 * bit[ax] + x, ex = c == 7 ? A + 32 + x : A + 16 * bit[ax] + y;
+            t0 = fmax(t0, (*reinterpret_cast<const double*>(b + en) - o[ax]) * inv[ax]);
+            t1 = fmin(t1, (*reinterpret_cast<const double*>(b + ex) - o[ax]) * inv[ax]);
+        }
+        return t1 > t0;
+    });
+    uint32_t m = (uint32_t)(group_ballot<G>(hit) & 0xffull) & exists;
+    if (wr.a & 1) m = ((m & 0x55u) << 1) | ((m >> 1) & 0x55u);
+    if (wr.a & 2) m = ((m & 0x33u) << 2) | ((m >> 2) & 0x33u);
+    if (wr.a & 4) m = ((m & 0x0fu) << 4) | ((m >> 4) & 0x0fu);
+    const float* cb = W.cbox_table(node);
+    if (m == 0u || !cb || wr.plain) return m;
+    // content boxes: lane k looks at the k-th child in the ray's order (content_cull's loop, a turn per lane)
+    uint32_t u = W.cuse_of(node);
+    if (wr.a & 1) u = ((u & 0x55u) << 1) | ((u >> 1) & 0x55u);
+    if (wr.a & 2) u = ((u & 0x33u) << 2) | ((u >> 2) & 0x33u);
+    if (wr.a & 4) u = ((u & 0x0fu) << 4) | ((u >> 4) & 0x0fu);
+    const uint32_t todo = m & u;
+    if (todo == 0u) return m;
+    bool miss = false;
+    if ((todo >> c) & 1u) {
+        const float* b = cb + ((size_t)node * 8 + (size_t)(c ^ wr.a)) * 6;
+        double tn = 0.0, tf = wr.tc;
+        for (int ax = 0; ax < 3; ax++) {
+            const int back = back_off(inv[ax]) ? 3 : 0;
+            tn = fmax(tn, ((double)b[ax + back] - o[ax]) * inv[ax]);
+            tf = fmin(tf, ((double)b[ax + 3 - back] - o[ax]) * inv[ax]);
+        }
+        miss = !(tf >= tn);
+    }
+    return m & ~(uint32_t)(group_ballot<G>(miss) & 0xffull);
+}
+#endif
+template <class WN>
+GI_HD uint32_t walk_hits(const WN& W, int32_t node, const Ray& ray, const WRay& wr, double tmin0, double tmax0)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (WN::kCoop) return walk_hits_coop(W, node, ray, wr, tmin0, tmax0);
+    else
+#endif
+    {
+        uint32_t m = W.with(node, [&](const WNode* w) { W.tick_node(w->exists); return wide_hits(w, ray, wr, tmin0, tmax0); });
+        if (m) m = W.cull(node, m, ray, wr);
+        return m;
+    }
+}
 // next non-empty leaf whose box the ray touches, or false when the tree is exhausted; leaf = (its parent's record, slot)
 template <class WN>
 GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr, double tmin0, double tmax0, int32_t& lnode, int& lslot, int32_t& first, int32_t& cnt)
@@ -812,8 +879,7 @@ GI_HD bool wwalk_next_leaf(const WN& W, WWalk& k, const Ray& ray, const WRay& wr
         if (cb < 0) {
             GI_DIV(W, 0);
             wwalk_push(k, ca);
-            k.m = W.with(ca, [&](const WNode* w) { W.tick_node(w->exists); return wide_hits(w, ray, wr, tmin0, tmax0); });
-            if (k.m) k.m = W.cull(ca, k.m, ray, wr);
+            k.m = walk_hits(W, ca, ray, wr, tmin0, tmax0);
             continue;
         }
         lnode = k.node; lslot = slot; first = ca; cnt = cb;
@@ -839,8 +905,7 @@ GI_HD int wwalk_turn(const WN& W, WWalk& k, const Ray& ray, const WRay& wr, doub
     if (cb < 0) {
         GI_DIV(W, 0);
         wwalk_push(k, ca);
-        k.m = W.with(ca, [&](const WNode* w) { W.tick_node(w->exists); return wide_hits(w, ray, wr, tmin0, tmax0); });
-        if (k.m) k.m = W.cull(ca, k.m, ray, wr);
+        k.m = walk_hits(W, ca, ray, wr, tmin0, tmax0);
         return WALK_MOVED;
     }
     lnode = k.node; lslot = slot; first = ca; cnt = cb;
@@ -852,8 +917,7 @@ GI_HD bool wwalk_begin(const Scene& S, const WN& W, WWalk& k, const Ray& ray, co
     k.node = 0; k.m = 0; k.lo = 0; k.hi = 0;
     W.tick_walk();
     if (!box_hit(S.root_bmin, S.root_bmax, ray, tmin0, tmax0)) return false;
-    k.m = W.with(0, [&](const WNode* w) { W.tick_node(w->exists); return wide_hits(w, ray, wr, tmin0, tmax0); });
-    if (k.m) k.m = W.cull(0, k.m, ray, wr);
+    k.m = walk_hits(W, 0, ray, wr, tmin0, tmax0);
     return true;
 }
 // RayTracer::trace over the wide records, one leaf per call: the streaming trace kernel keeps a wave's lanes on different rays and hands a
@@ -1114,7 +1178,7 @@ __device__ __forceinline__ bool trace_wide_coop(const Scene& S, const WN& W, con
     else {
     constexpr int G = WN::kGroup;
     const int lane = (int)(threadIdx.x & 63u), gl = lane & (G - 1), gb = lane - gl;
-    const WRay wr = wray_make(ray);
+    WRay wr = wray_make(ray);
     bool intersected = false;
     double best_d2 = 0;
     WWalk k;
@@ -1122,7 +1186,7 @@ __device__ __forceinline__ bool trace_wide_coop(const Scene& S, const WN& W, con
     for (;;) {
         int32_t lnode = 0, first = 0, cnt = 0;
         int lslot = 0;
-        if (!wwalk_next_leaf(W, k, ray, wr, 0.0, INFINITY, lnode, lslot, first, cnt)) break;
+        if (!wwalk_next_leaf(W, k, ray, wr, 0.0, wr.tc, lnode, lslot, first, cnt)) break;
         bool term = false;
         double lmin[3], lmax[3];
         W.with(lnode, [&](const WNode* w) { wide_leaf_box(w, lslot, lmin, lmax); return 0; });
@@ -1161,6 +1225,8 @@ __device__ __forceinline__ bool trace_wide_coop(const Scene& S, const WN& W, con
                 best.tri = __shfl(ti, last); best.mf = (uint32_t)__shfl((int)mf, last);
                 best_d2 = __shfl(d2, last);
                 intersected = true;
+                if (S.cut_margin >= 0) wr.tc = sqrt(best_d2) + S.cut_margin;   // no look behind the best hit (trace_wide_step): the reference walks on to the end of the ray
+                                                                              // when the hit was found from an earlier leaf -- a lone path inside a glass body does that at every bounce
             }
         }
         if (term) break;

@@ -166,6 +166,9 @@ struct LdsWideT {
         tick_cull(nt);
         return res;
     }
+    // the tables cull() reads, for callers that test a record's children side by side (gi_device.h: walk_hits of the one-ray-per-group walks)
+    __device__ __forceinline__ const float* cbox_table(int32_t node) const { return !cboxes ? nullptr : (node < n_lc ? reinterpret_cast<const float*>(gi_dyn_lds + box_off) : cboxes); }
+    __device__ __forceinline__ uint32_t cuse_of(int32_t node) const { return node < n_lc ? reinterpret_cast<const uint32_t*>(gi_dyn_lds + use_off)[node] : cuse[node]; }
 };
 typedef LdsWideT<false> LdsWide;
 #ifdef GI_EXP_DIV
@@ -1563,7 +1566,7 @@ __global__ __launch_bounds__(GI_FINISH_BLOCK) void k_st_finish(Scene S, uint64_t
                 int fl = 0;
                 if (running) {
                     if (!stage_trace_nodes<FEAT>(S, NC, p, seed, nullptr)) { alive = false; running = false; }
-                    else fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
+                    if (running) fl = stage_shade_nodes<FEAT>(S, NC, p, seed, nullptr);
                 }
                 finish_gathers(S, p, running && (fl & ST_GATHER) != 0, G, heap, heap_stride, heap32, lane);
                 if (running && !(fl & ST_CONTINUE)) { alive = false; running = false; }
