@@ -2060,9 +2060,14 @@ struct Frame {
     int32_t stripe_h, stripe_rank, stripe_world, local_rows;
 };
 // primary ray of sample s of pixel (x,y): include/raytracer.h:112-129 (FOCAL_BLUR == 0)
+GI_HD Ray primary_ray_at(const Scene& S, const Frame& F, uint32_t idx);
 GI_HD Ray primary_ray(const Scene& S, const Frame& F, int s, int x, int y, uint32_t& idx)
 {
     idx = halton_index(F.he, (uint32_t)s, (uint32_t)x, (uint32_t)y);
+    return primary_ray_at(S, F, idx);
+}
+GI_HD Ray primary_ray_at(const Scene& S, const Frame& F, uint32_t idx)   // the ray of the sample with Halton index idx (the index names the pixel too: Halton_enum)
+{
     double xr = halton_sample(S, 0, idx);
     double yr = halton_sample(S, 1, idx);
     double dx = (float)((float)xr * F.he.scale_x);

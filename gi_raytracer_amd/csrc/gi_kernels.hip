@@ -600,13 +600,28 @@ __device__ __forceinline__ void st_release(uint32_t slot, uint32_t* q_free, unsi
 // i-th free slot and sample id g.id_base + i, builds its primary ray in registers and traces it at once -- a primary ray that misses
 // never exists in memory (its radiance goes straight to lbuf and the slot straight back to the free list), one that hits is stored
 // together with its hit.  Sample ids are consecutive per lane = neighbouring pixels of one 8x8 tile, so these waves are coherent.
+// What a new path of pixel p needs before its ray can be made -- the pixel's place in the frame (st_pixel_xy: four divisions by run-time numbers) and
+// the Halton index of its first sample (halton_index: a 64-bit remainder) -- is the same for all the samples of the pixel: one table per frame instead
+// of ~300 instructions per primary ray.
+__global__ void k_pixel_table(Frame F, uint32_t n_pix, uint32_t* out);
 struct GenArgs {
     Frame F;
     const uint32_t* q_free;           // free slots to fill (nullptr: slots 0 .. n_gen - 1)
     uint32_t n_gen, n_pix;
     unsigned long long id_base, sample_begin;
     int s_begin;
+    const uint32_t* pixtab;           // per pixel of this rank, tile order: the Halton index of its sample 0 (k_pixel_table)
+    double inv_n_pix;
 };
+__global__ void k_pixel_table(Frame F, uint32_t n_pix, uint32_t* out)
+{
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n_pix; p += gridDim.x * blockDim.x) {
+        int x, ly;
+        st_pixel_xy(F, p, x, ly);
+        const int y = global_row(F, ly);
+        out[p] = halton_index(F.he, 0u, (uint32_t)x, (uint32_t)y);
+    }
+}
 // Wide-record instances keep the lanes of a wave on DIFFERENT rays: a lane whose walk is over waits until `refill_min` lanes of its wave
 // are idle, then the idle lanes write their results and take the next items of the workgroup's share of the queue (an LDS counter), while
 // the others walk on -- a wave no longer runs at the pace of its longest ray with the other lanes switched off (closed scenes: a third
@@ -637,10 +652,12 @@ __global__ __launch_bounds__(GI_TRACE_BLOCK) void k_st_trace(Scene S, uint64_t s
             slot = g.q_free ? g.q_free[i] : i;
             const unsigned long long id = g.id_base + i;
             // ids of one chunk span less than 2^32 (the radiance buffer bounds the chunk): 32-bit division instead of 64-bit
-            const uint32_t rel = (uint32_t)(id - g.sample_begin), srel = rel / g.n_pix;
-            int x, ly;
-            st_pixel_xy(g.F, rel - srel * g.n_pix, x, ly);
-            ray = primary_ray(S, g.F, g.s_begin + (int)srel, x, global_row(g.F, ly), stream);
+            const uint32_t rel = (uint32_t)(id - g.sample_begin);
+            uint32_t srel = (uint32_t)((double)rel * g.inv_n_pix);               // rel / n_pix: the quotient of the doubles, put right by one step either way
+            if ((unsigned long long)srel * g.n_pix > rel) srel--;
+            else if ((unsigned long long)(srel + 1u) * g.n_pix <= rel) srel++;
+            stream = g.pixtab[rel - srel * g.n_pix] + (uint32_t)(g.s_begin + (int)srel) * g.F.he.inc;        // halton_index(he, s, x, y) = its value for s = 0 + s * inc
+            ray = primary_ray_at(S, g.F, stream);
             depth = 0;
         } else {
             slot = i - g.n_gen < n_a ? q_a[i - g.n_gen] : q_b[i - g.n_gen - n_a];
@@ -1847,6 +1864,7 @@ struct gi_ctx {
     DevBuf<Counters> d_counters;
     // wavefront pipeline workspaces (grown on demand, kept between frames)
     DevBuf<PathRec> d_pool;               // paths of the round-based wavefront pipeline (records)
+    DevBuf<uint32_t> d_pixtab;               // k_pixel_table of the frame being rendered
     DevBuf<unsigned char> d_spool;        // paths of the streaming pipeline: field arrays (PathPool), GI_POOL_BYTES_PER_SLOT each
     size_t spool_slots = 0;
     DevBuf<PixRec> d_pix;
@@ -2542,7 +2560,9 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
     }
     HIP_TRY(c, hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(k_wf_init, dim3(G.init), dim3(GI_BLOCK), 0, st, c->d_pix.p, n_pix);
-    launches++;
+    if (c->d_pixtab.n < n_pix) HIP_TRY(c, c->d_pixtab.alloc(n_pix));
+    hipLaunchKernelGGL(k_pixel_table, dim3(G.init), dim3(GI_BLOCK), 0, st, F, n_pix, c->d_pixtab.p);
+    launches += 2;
     for (int s0 = 0; s0 < spp; s0 += chunk) {
         const int ns = std::min(chunk, spp - s0);
         const unsigned long long sample0 = (unsigned long long)s0 * n_pix, sample_end = (unsigned long long)(s0 + ns) * n_pix;
@@ -2551,6 +2571,7 @@ static int render_streaming(gi_ctx* c, const Frame& F, void* d_out, int out_is_f
         auto refill = [&](uint32_t n_free, const uint32_t* qf, GenArgs& gen) -> uint32_t {   // path regeneration: free slots take the next samples
             const uint32_t n_new = (uint32_t)std::min<unsigned long long>(n_free, sample_end - next);
             gen.q_free = qf; gen.n_gen = n_new; gen.n_pix = n_pix; gen.id_base = next; gen.sample_begin = sample0; gen.s_begin = s0;
+            gen.pixtab = c->d_pixtab.p; gen.inv_n_pix = 1.0 / (double)n_pix;
             next += n_new;
             exhausted = next >= sample_end;
             return 0;                                                                          // nothing prepared: the trace kernel starts them
