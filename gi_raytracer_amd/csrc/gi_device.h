@@ -983,9 +983,7 @@ GI_HD bool trace_wide_step(const Scene& S, const WN& W, const Ray& ray, const Rn
             if (!(rng_draw(rng, alpha_purpose, (uint32_t)S.wleaf_id[lnode * 8 + lslot], (uint32_t)ti) < alpha || m.ior != 1)) return;
         }
         double d2 = len2(hp - ray.o);
-#ifndef GI_EXP_NOTIE
         if (t.intersected && d2 == t.best_d2 && ti != best.tri) t.tie = true;
-#endif
         if (!t.intersected || d2 < t.best_d2) {
             best.pos = hp; best.u = u; best.v = v; best.tri = ti; best.mf = g.matflags;
             if (FEAT & GI_FEAT_TEX) { best.tu = t.cu; best.tv = t.cv; }
